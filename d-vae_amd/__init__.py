@@ -1,0 +1,11 @@
+"""dvae_amd -- MI355X-native D-VAE train-step hot path.
+
+The directory is called `d-vae_amd` (not an importable identifier); load it with
+`from _dvae_pkg import dvae_amd` (repo root helper) which registers it in
+sys.modules as `dvae_amd`.
+"""
+from .batching import DAGBatch, GraphArrays, graphs_to_arrays, shard_bounds  # noqa: F401
+from .models import DVAE, DVAE_BN, PARAM_NAMES  # noqa: F401
+from . import _lib  # noqa: F401
+
+__all__ = ["DVAE", "DVAE_BN", "DAGBatch", "GraphArrays", "graphs_to_arrays", "shard_bounds", "PARAM_NAMES"]

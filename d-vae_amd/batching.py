@@ -1,0 +1,140 @@
+"""DAG batching: graphs -> packed index tables on the device.
+
+Replaces the reference's batching, which is a Python list of igraph copies
+(`/root/reference/models.py:631-632`), the per-vertex filter / gather / zero-pad
+of `models.py:637-668`, and `custom_DataParallel.scatter` (`util.py:557-573`).
+
+Input graphs are duck-typed (python-igraph is not required): any object with
+`vcount()`, `vs['type']` and `get_adjlist(mode)` / `predecessors(v)`; vertex ids
+must be a topological order (`models.py:677`).  Graphs can also be given as plain
+arrays (`GraphArrays`), which is what a pre-packed dataset keeps.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+IGRAPH_IN = 2  # igraph.IN
+
+
+class GraphArrays(object):
+    """A set of DAGs as arrays: types [N, max_n] int32, pred_mask [N, max_n] uint64
+    (bit u of pred_mask[g, v] <=> edge u -> v), n_vertices [N] int32."""
+
+    def __init__(self, types, pred_mask, n_vertices, max_n):
+        self.types = np.ascontiguousarray(types, dtype=np.int32)
+        self.pred_mask = np.ascontiguousarray(pred_mask, dtype=np.uint64)
+        self.n_vertices = np.ascontiguousarray(n_vertices, dtype=np.int32)
+        self.max_n = int(max_n)
+        if self.types.shape != self.pred_mask.shape or self.types.shape[1] != self.max_n:
+            raise ValueError("types / pred_mask must both be [N, max_n]")
+
+    def __len__(self):
+        return self.types.shape[0]
+
+    def select(self, index):
+        index = np.asarray(index)
+        return GraphArrays(self.types[index], self.pred_mask[index], self.n_vertices[index], self.max_n)
+
+    def __getitem__(self, s):
+        if isinstance(s, slice):
+            return GraphArrays(self.types[s], self.pred_mask[s], self.n_vertices[s], self.max_n)
+        return self.select(s)
+
+    def to_dense(self):
+        """-> types int64 [N, n], adj uint8 [N, n, n], n_g int64 [N] (oracle format)"""
+        N, n = self.types.shape
+        adj = np.zeros((N, n, n), np.uint8)
+        for u in range(n):
+            adj[:, u, :] = ((self.pred_mask >> np.uint64(u)) & np.uint64(1)).astype(np.uint8)
+        return self.types.astype(np.int64), adj, self.n_vertices.astype(np.int64)
+
+    @staticmethod
+    def from_dense(types, adj, n_g):
+        types = np.asarray(types)
+        adj = np.asarray(adj)
+        N, n = types.shape
+        mask = np.zeros((N, n), np.uint64)
+        for u in range(n):
+            mask |= (adj[:, u, :].astype(np.uint64) << np.uint64(u))
+        return GraphArrays(types, mask, n_g, n)
+
+
+def graphs_to_arrays(graphs, max_n):
+    """igraph-like objects -> GraphArrays.  Raises ValueError on graphs that do
+    not fit (too many vertices, vertex ids not a topological order)."""
+    if isinstance(graphs, GraphArrays):
+        if graphs.max_n != max_n:
+            raise ValueError("GraphArrays packed for max_n=%d, model has max_n=%d" % (graphs.max_n, max_n))
+        return graphs
+    if max_n > 64:
+        raise ValueError("max_n > 64 is not supported (predecessor bitmask is 64 bits)")
+    N = len(graphs)
+    types = np.zeros((N, max_n), np.int32)
+    mask = np.zeros((N, max_n), np.uint64)
+    n_g = np.zeros((N,), np.int32)
+    for i, g in enumerate(graphs):
+        k = g.vcount()
+        if k > max_n:
+            raise ValueError("graph %d has %d vertices, max_n is %d" % (i, k, max_n))
+        if k < 1:
+            raise ValueError("graph %d is empty" % i)
+        n_g[i] = k
+        types[i, :k] = g.vs["type"]
+        if hasattr(g, "get_adjlist"):
+            adjl = g.get_adjlist(IGRAPH_IN)
+        else:
+            adjl = [g.predecessors(v) for v in range(k)]
+        for v, preds in enumerate(adjl):
+            m = 0
+            for u in preds:
+                if u >= v:
+                    raise ValueError("graph %d: edge %d -> %d violates the topological vertex order" % (i, u, v))
+                m |= (1 << int(u))
+            mask[i, v] = m
+    return GraphArrays(types, mask, n_g, max_n)
+
+
+class DAGBatch(object):
+    """A packed batch: host arrays + the device index blob the kernels read."""
+
+    def __init__(self, arrays, nvt, start_type, is_bn, device):
+        lib = _lib.load()
+        self.arrays = arrays
+        self.B = len(arrays)
+        self.max_n = arrays.max_n
+        self.nvt = int(nvt)
+        self.is_bn = bool(is_bn)
+        if self.B == 0:
+            raise ValueError("empty batch")
+        counts = _lib.BatchCounts()
+        handle = C.c_void_p()
+        _lib.check(lib.dvae_batch_create(self.B, self.max_n, self.nvt, int(start_type), int(self.is_bn),
+                                         _lib.ptr(arrays.types), _lib.ptr(arrays.pred_mask),
+                                         _lib.ptr(arrays.n_vertices), C.byref(handle), C.byref(counts)),
+                   "dvae_batch_create")
+        try:
+            host = torch.empty(int(counts.total_ints), dtype=torch.int32)
+            _lib.check(lib.dvae_batch_export(handle, host.data_ptr(), counts.total_ints), "dvae_batch_export")
+        finally:
+            lib.dvae_batch_destroy(handle)
+        self.counts = counts
+        self.blob_host = host
+        self.device = torch.device(device)
+        self.blob = host.to(self.device, non_blocking=False) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return self.B
+
+    def edges(self):
+        return int(self.counts.E)
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous ceil-split of a batch over ranks, the rule of
+    custom_DataParallel.scatter (util.py:566-572)."""
+    chunk = -(-n_items // world_size)
+    lo = min(rank * chunk, n_items)
+    return lo, min(lo + chunk, n_items)

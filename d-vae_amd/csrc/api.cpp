@@ -1,0 +1,20 @@
+// Error reporting and version of the C-ABI.
+#include "common.h"
+#include "dvae_hip.h"
+
+namespace dvae {
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace dvae
+
+extern "C" const char* dvae_last_error(void) { return dvae::err_buf(); }
+extern "C" int dvae_version(void) { return 100; }

@@ -1,0 +1,91 @@
+// Model dimensions, parameter indices and the packed (zero-padded) weight layout.
+#pragma once
+#include <stddef.h>
+#include "common.h"
+#include "dvae_hip.h"
+
+namespace dvae {
+
+// state_dict order of models.DVAE / DVAE_BN
+enum ParamId {
+    P_EF_WIH = 0, P_EF_WHH, P_EF_BIH, P_EF_BHH,
+    P_EB_WIH, P_EB_WHH, P_EB_BIH, P_EB_BHH,
+    P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B,
+    P_D_WIH, P_D_WHH, P_D_BIH, P_D_BHH,
+    P_FC3_W, P_FC3_B,
+    P_AV0_W, P_AV0_B, P_AV2_W, P_AV2_B,
+    P_AE0_W, P_AE0_B, P_AE2_W, P_AE2_B,
+    P_GF_W, P_GF_B, P_GB_W, P_GB_B,
+    P_MF_W, P_MB_W,
+    P_HV_W, P_HV_B, P_HG_W, P_HG_B,
+    P_COUNT
+};
+static_assert(P_COUNT == DVAE_NUM_PARAMS, "parameter table size");
+
+struct Dims {
+    int n, T, H, nz, bidir, vid, bn, start_type;
+    int Hp, NZp, Tp, HVp, HEp, V;
+};
+
+static inline int make_dims(const dvae_model_desc* m, Dims& d) {
+    DVAE_REQUIRE(m != nullptr, "null model descriptor");
+    DVAE_REQUIRE(m->max_n >= 2 && m->max_n <= 64, "max_n must be in 2..64 (got %d)", m->max_n);
+    DVAE_REQUIRE(m->nvt >= 2 && m->nvt <= 32, "nvt must be in 2..32 (got %d)", m->nvt);
+    DVAE_REQUIRE(m->hs >= 1 && m->nz >= 1, "hs and nz must be positive");
+    d.n = m->max_n; d.T = m->nvt; d.H = m->hs; d.nz = m->nz;
+    d.bidir = m->bidir != 0; d.bn = m->is_bn != 0; d.vid = (m->vid != 0) && !d.bn;
+    d.start_type = m->start_type;
+    d.Hp = round_up(d.H, 32);
+    d.NZp = round_up(d.nz, 32);
+    d.Tp = 32;
+    d.HVp = 2 * d.Hp;
+    d.HEp = d.bn ? d.Hp : 4 * d.Hp;
+    d.V = d.bn ? d.T : (d.vid ? d.H + d.n : d.H);
+    return DVAE_OK;
+}
+
+// offsets (in floats) into the packed weight buffer; the packed GRADIENT buffer
+// uses the same layout (gi -> d gi_tab, gv -> d gv, gtab -> d gtab, ...).
+struct PackedLayout {
+    size_t whh[3], gi[3], bhn[3];        // GRUs: 0 enc fwd, 1 enc bwd, 2 dec.  [3Hp][Hp], [Tp][3Hp], [Hp]
+    size_t wgm[2], gv[2];                // gate|mapper h-part [2Hp][Hp], vertex-id table [n][2Hp]   (DVAE)
+    size_t gtab[2], gtg[2], gtm[2];      // BN message tables [Tp][Hp]: g*m, g, m
+    size_t fc12, b12, fc3, b3;           // [2NZp][Hp], [2NZp], [Hp][NZp], [Hp]
+    size_t wv1, bv1, wv2, bv2;           // [2Hp][Hp], [2Hp], [Tp][2Hp], [Tp]
+    size_t w1a, w1b, w1c, be1, we2, be2; // [HEp][Hp] x3, [HEp], [HEp], [4]
+    size_t wu, bu;                       // [Hp][2Hp], [Hp]
+    size_t total;
+};
+
+static inline PackedLayout make_layout(const Dims& d) {
+    PackedLayout L;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    const size_t Hp = d.Hp;
+    for (int g = 0; g < 3; ++g) { L.whh[g] = take(3 * Hp * Hp); L.gi[g] = take((size_t)d.Tp * 3 * Hp); L.bhn[g] = take(Hp); }
+    for (int k = 0; k < 2; ++k) {
+        L.wgm[k] = take(2 * Hp * Hp);
+        L.gv[k] = take((size_t)d.n * 2 * Hp);
+        L.gtab[k] = take((size_t)d.Tp * Hp);
+        L.gtg[k] = take((size_t)d.Tp * Hp);
+        L.gtm[k] = take((size_t)d.Tp * Hp);
+    }
+    L.fc12 = take((size_t)2 * d.NZp * Hp); L.b12 = take(2 * d.NZp);
+    L.fc3 = take(Hp * d.NZp); L.b3 = take(Hp);
+    L.wv1 = take((size_t)d.HVp * Hp); L.bv1 = take(d.HVp);
+    L.wv2 = take((size_t)d.Tp * d.HVp); L.bv2 = take(d.Tp);
+    L.w1a = take((size_t)d.HEp * Hp); L.w1b = take((size_t)d.HEp * Hp); L.w1c = take((size_t)d.HEp * Hp);
+    L.be1 = take(d.HEp); L.we2 = take(d.HEp); L.be2 = take(4);
+    L.wu = take(Hp * 2 * Hp); L.bu = take(Hp);
+    L.total = o;
+    return L;
+}
+
+// internal kernels shared between translation units
+int gemm(const dvae_gemm_desc& d, hipStream_t s);
+int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
+                    float* kld_sum, int B, int nz, int NZp, hipStream_t s);
+int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training,
+                    const float* dz, const float* gk, float* dmu, float* dlogvar, int B, int nz, int NZp, hipStream_t s);
+
+}  // namespace dvae

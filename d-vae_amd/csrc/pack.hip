@@ -1,0 +1,267 @@
+// Weight packing (native state_dict tensors -> zero-padded, MFMA-friendly
+// layout) and gradient unpacking (the exact transpose of the same maps).
+// Padding is exact: padded GRU lanes stay 0 (n = tanh(0) = 0, h' = z*0), padded
+// gate lanes multiply a zero mapper lane (models.py:585-586 keeps the mapper
+// bias-free for the same reason).
+#include "common.h"
+#include "model.h"
+
+namespace dvae {
+
+struct CopyOp {
+    const float* src;
+    float* dst;
+    int rows, cols, src_ld, dst_ld;
+};
+constexpr int MAX_OPS = 48;
+struct CopyOps {
+    CopyOp op[MAX_OPS];
+    int n;
+};
+
+__global__ void copy_ops_kernel(CopyOps ops) {
+    const CopyOp& o = ops.op[blockIdx.y];
+    long total = (long)o.rows * o.cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / o.cols), c = (int)(i % o.cols);
+        o.dst[(long)r * o.dst_ld + c] = o.src[(long)r * o.src_ld + c];
+    }
+}
+
+// gi[t][q*Hp + j] = Wih[q*H + j][t] + bih[q*H + j] + (q < 2 ? bhh[q*H + j] : 0)
+__global__ void build_gi_kernel(float* gi, const float* wih, const float* bih, const float* bhh, int T, int H, int Hp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * 3 * H) return;
+    int t = i / (3 * H), r = i % (3 * H), q = r / H, j = r % H;
+    float v = wih[(long)r * T + t] + bih[r] + (q < 2 ? bhh[r] : 0.f);
+    gi[(long)t * 3 * Hp + q * Hp + j] = v;
+}
+__global__ void unbuild_gi_kernel(const float* dgi, const float* dbhn, float* dwih, float* dbih, float* dbhh, int T,
+                                  int H, int Hp) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 3 * H) return;
+    int q = r / H, j = r % H;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float v = dgi[(long)t * 3 * Hp + q * Hp + j];
+        if (dwih) dwih[(long)r * T + t] = v;
+        s += v;
+    }
+    if (dbih) dbih[r] = s;
+    if (dbhh) dbhh[r] = q < 2 ? s : dbhn[j];
+}
+
+// gv[v][j] = (vid ? Wg[j][H+v] : 0) + bg[j];  gv[v][Hp+j] = vid ? Wm[j][H+v] : 0
+__global__ void build_gv_kernel(float* gv, const float* wg, const float* bg, const float* wm, int n, int H, int Hp,
+                                int V, int vid) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * H) return;
+    int v = i / H, j = i % H;
+    gv[(long)v * 2 * Hp + j] = (vid ? wg[(long)j * V + H + v] : 0.f) + bg[j];
+    gv[(long)v * 2 * Hp + Hp + j] = vid ? wm[(long)j * V + H + v] : 0.f;
+}
+__global__ void unbuild_gv_kernel(const float* dgv, float* dwg, float* dbg, float* dwm, int n, int H, int Hp, int V,
+                                  int vid) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    float s = 0.f;
+    for (int v = 0; v < n; ++v) {
+        float a = dgv[(long)v * 2 * Hp + j];
+        s += a;
+        if (vid) {
+            if (dwg) dwg[(long)j * V + H + v] = a;
+            if (dwm) dwm[(long)j * V + H + v] = dgv[(long)v * 2 * Hp + Hp + j];
+        }
+    }
+    if (dbg) dbg[j] = s;
+}
+
+// BN message table: gated(u) = sigmoid(Wg[:, t_u] + bg) * Wm[:, t_u]  (models.py:1044-1062)
+__global__ void build_bn_table_kernel(float* gtab, float* gtg, float* gtm, const float* wg, const float* bg,
+                                      const float* wm, int T, int H, int Hp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * H) return;
+    int t = i / H, j = i % H;
+    float g = 1.f / (1.f + expf(-(wg[(long)j * T + t] + bg[j])));
+    float m = wm[(long)j * T + t];
+    gtg[(long)t * Hp + j] = g;
+    gtm[(long)t * Hp + j] = m;
+    gtab[(long)t * Hp + j] = g * m;
+}
+__global__ void unbuild_bn_table_kernel(const float* dgtab, const float* gtg, const float* gtm, float* dwg, float* dbg,
+                                        float* dwm, int T, int H, int Hp) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float d = dgtab[(long)t * Hp + j], g = gtg[(long)t * Hp + j], m = gtm[(long)t * Hp + j];
+        float da = d * m * g * (1.f - g);
+        s += da;
+        if (dwg) dwg[(long)j * T + t] = da;
+        if (dwm) dwm[(long)j * T + t] = d * g;
+    }
+    if (dbg) dbg[j] = s;
+}
+
+// native <-> packed block copies.  `nat[i]` may be null (absent parameter).
+// to_packed: native -> packed ; else packed -> native.
+static int block_ops(const Dims& d, const PackedLayout& L, float* const* nat, float* pk, bool to_packed, CopyOps& ops,
+                     const bool* want /* nullable: which params to touch */) {
+    ops.n = 0;
+    const int H = d.H, Hp = d.Hp;
+    auto add = [&](int pid, size_t nat_off, int nat_ld, size_t pk_off, int pk_ld, int rows, int cols) {
+        if (!nat[pid] || (want && !want[pid])) return;
+        CopyOp o;
+        if (to_packed) { o.src = nat[pid] + nat_off; o.dst = pk + pk_off; o.src_ld = nat_ld; o.dst_ld = pk_ld; }
+        else { o.src = pk + pk_off; o.dst = nat[pid] + nat_off; o.src_ld = pk_ld; o.dst_ld = nat_ld; }
+        o.rows = rows; o.cols = cols;
+        ops.op[ops.n++] = o;
+    };
+    const int gru_w[3] = {P_EF_WHH, P_EB_WHH, P_D_WHH};
+    for (int g = 0; g < 3; ++g)
+        for (int q = 0; q < 3; ++q) add(gru_w[g], (size_t)q * H * H, H, L.whh[g] + (size_t)q * Hp * Hp, Hp, H, H);
+    // b_hh of the n gate stays a separate vector (it sits inside r * (W_hn h + b_hn)); its
+    // gradient is routed by unbuild_gi_kernel, so the copy exists in the packing direction only
+    if (to_packed)
+        for (int g = 0; g < 3; ++g) add(gru_w[g] + 2, (size_t)2 * H, H, L.bhn[g], H, 1, H);
+    if (!d.bn) {
+        const int gw[2] = {P_GF_W, P_GB_W}, mw[2] = {P_MF_W, P_MB_W};
+        for (int k = 0; k < 2; ++k) {
+            add(gw[k], 0, d.V, L.wgm[k], Hp, H, H);
+            add(mw[k], 0, d.V, L.wgm[k] + (size_t)Hp * Hp, Hp, H, H);
+        }
+    }
+    add(P_FC1_W, 0, H, L.fc12, Hp, d.nz, H);
+    add(P_FC2_W, 0, H, L.fc12 + (size_t)d.NZp * Hp, Hp, d.nz, H);
+    add(P_FC1_B, 0, d.nz, L.b12, d.nz, 1, d.nz);
+    add(P_FC2_B, 0, d.nz, L.b12 + d.NZp, d.nz, 1, d.nz);
+    add(P_FC3_W, 0, d.nz, L.fc3, d.NZp, H, d.nz);
+    add(P_FC3_B, 0, H, L.b3, H, 1, H);
+    add(P_AV0_W, 0, H, L.wv1, Hp, 2 * H, H);
+    add(P_AV0_B, 0, 2 * H, L.bv1, 2 * H, 1, 2 * H);
+    add(P_AV2_W, 0, 2 * H, L.wv2, d.HVp, d.T, 2 * H);
+    add(P_AV2_B, 0, d.T, L.bv2, d.T, 1, d.T);
+    if (d.bn) {
+        add(P_AE0_W, 0, 3 * H, L.w1a, Hp, H, H);
+        add(P_AE0_W, H, 3 * H, L.w1b, Hp, H, H);
+        add(P_AE0_W, 2 * H, 3 * H, L.w1c, Hp, H, H);
+        add(P_AE0_B, 0, H, L.be1, H, 1, H);
+        add(P_AE2_W, 0, H, L.we2, H, 1, H);
+    } else {
+        add(P_AE0_W, 0, 2 * H, L.w1a, Hp, 4 * H, H);
+        add(P_AE0_W, H, 2 * H, L.w1b, Hp, 4 * H, H);
+        add(P_AE0_B, 0, 4 * H, L.be1, 4 * H, 1, 4 * H);
+        add(P_AE2_W, 0, 4 * H, L.we2, 4 * H, 1, 4 * H);
+    }
+    add(P_AE2_B, 0, 1, L.be2, 1, 1, 1);
+    if (d.bidir) {
+        add(P_HG_W, 0, 2 * H, L.wu, 2 * Hp, H, H);
+        add(P_HG_W, H, 2 * H, L.wu + Hp, 2 * Hp, H, H);
+        add(P_HG_B, 0, H, L.bu, H, 1, H);
+    }
+    if (ops.n > MAX_OPS) return set_err(DVAE_ERR_SIZE, "copy-op table overflow");
+    return DVAE_OK;
+}
+
+static int run_ops(const CopyOps& ops, hipStream_t s) {
+    if (ops.n == 0) return DVAE_OK;
+    hipLaunchKernelGGL(copy_ops_kernel, dim3(64, ops.n), dim3(256), 0, s, ops);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+int check_params(const Dims& d, const float* const* p) {
+    const int need_always[] = {P_EF_WIH, P_EF_WHH, P_EF_BIH, P_EF_BHH, P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B,
+                               P_D_WIH, P_D_WHH, P_D_BIH, P_D_BHH, P_FC3_W, P_FC3_B, P_AV0_W, P_AV0_B, P_AV2_W,
+                               P_AV2_B, P_AE0_W, P_AE0_B, P_AE2_W, P_AE2_B, P_GF_W, P_GF_B, P_MF_W};
+    for (int id : need_always) DVAE_REQUIRE(p[id] != nullptr, "parameter %d is required but null", id);
+    if (d.bidir) {
+        const int need_bi[] = {P_EB_WIH, P_EB_WHH, P_EB_BIH, P_EB_BHH, P_GB_W, P_GB_B, P_MB_W, P_HG_W, P_HG_B};
+        for (int id : need_bi) DVAE_REQUIRE(p[id] != nullptr, "parameter %d is required for bidirectional but null", id);
+    }
+    return DVAE_OK;
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" int64_t dvae_packed_floats(const dvae_model_desc* m) {
+    Dims d;
+    if (make_dims(m, d) != 0) return -1;
+    return (int64_t)make_layout(d).total;
+}
+
+extern "C" int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_REQUIRE(params && packed, "dvae_pack_weights: null pointer");
+    DVAE_TRY(check_params(d, params));
+    hipStream_t s = (hipStream_t)stream;
+    PackedLayout L = make_layout(d);
+    DVAE_HIP(hipMemsetAsync(packed, 0, L.total * sizeof(float), s));
+    CopyOps ops;
+    DVAE_TRY(block_ops(d, L, const_cast<float* const*>(reinterpret_cast<const float* const*>(params)), packed, true, ops, nullptr));
+    DVAE_TRY(run_ops(ops, s));
+    const int wih[3] = {P_EF_WIH, P_EB_WIH, P_D_WIH};
+    for (int g = 0; g < 3; ++g) {
+        if (!params[wih[g]]) continue;
+        hipLaunchKernelGGL(build_gi_kernel, dim3(cdiv(d.T * 3 * d.H, 256)), dim3(256), 0, s, packed + L.gi[g],
+                           params[wih[g]], params[wih[g] + 2], params[wih[g] + 3], d.T, d.H, d.Hp);
+    }
+    const int gw[2] = {P_GF_W, P_GB_W}, gb[2] = {P_GF_B, P_GB_B}, mw[2] = {P_MF_W, P_MB_W};
+    for (int k = 0; k < 2; ++k) {
+        if (!params[gw[k]] || !params[gb[k]] || !params[mw[k]]) continue;
+        if (d.bn) {
+            hipLaunchKernelGGL(build_bn_table_kernel, dim3(cdiv(d.T * d.H, 256)), dim3(256), 0, s, packed + L.gtab[k],
+                               packed + L.gtg[k], packed + L.gtm[k], params[gw[k]], params[gb[k]], params[mw[k]], d.T,
+                               d.H, d.Hp);
+        } else {
+            hipLaunchKernelGGL(build_gv_kernel, dim3(cdiv(d.n * d.H, 256)), dim3(256), 0, s, packed + L.gv[k],
+                               params[gw[k]], params[gb[k]], params[mw[k]], d.n, d.H, d.Hp, d.V, d.vid);
+        }
+    }
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+// packed gradient buffer -> native gradient tensors.  `want[i]` != 0 selects the
+// parameters this call produces (others untouched); grads[i] may be null.
+extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const float* packed_g,
+                                 float* const* grads, const uint8_t* want, void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_REQUIRE(packed_g && grads && want, "dvae_unpack_grads: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    PackedLayout L = make_layout(d);
+    bool w[P_COUNT];
+    for (int i = 0; i < P_COUNT; ++i) w[i] = want[i] != 0 && grads[i] != nullptr;
+    CopyOps ops;
+    DVAE_TRY(block_ops(d, L, grads, const_cast<float*>(packed_g), false, ops, w));
+    DVAE_TRY(run_ops(ops, s));
+    const int wih[3] = {P_EF_WIH, P_EB_WIH, P_D_WIH};
+    for (int g = 0; g < 3; ++g) {
+        int a = wih[g];
+        if (!(w[a] || w[a + 2] || w[a + 3])) continue;
+        hipLaunchKernelGGL(unbuild_gi_kernel, dim3(cdiv(3 * d.H, 256)), dim3(256), 0, s, packed_g + L.gi[g],
+                           packed_g + L.bhn[g], w[a] ? grads[a] : nullptr, w[a + 2] ? grads[a + 2] : nullptr,
+                           w[a + 3] ? grads[a + 3] : nullptr, d.T, d.H, d.Hp);
+    }
+    const int gw[2] = {P_GF_W, P_GB_W}, gb[2] = {P_GF_B, P_GB_B}, mw[2] = {P_MF_W, P_MB_W};
+    for (int k = 0; k < 2; ++k) {
+        if (!(w[gw[k]] || w[gb[k]] || w[mw[k]])) continue;
+        float* dwg = w[gw[k]] ? grads[gw[k]] : nullptr;
+        float* dbg = w[gb[k]] ? grads[gb[k]] : nullptr;
+        float* dwm = w[mw[k]] ? grads[mw[k]] : nullptr;
+        if (d.bn) {
+            DVAE_REQUIRE(packed_w != nullptr, "dvae_unpack_grads: BN needs the packed weights (gate tables)");
+            hipLaunchKernelGGL(unbuild_bn_table_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gtab[k],
+                               packed_w + L.gtg[k], packed_w + L.gtm[k], dwg, dbg, dwm, d.T, d.H, d.Hp);
+        } else {
+            hipLaunchKernelGGL(unbuild_gv_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gv[k], dwg, dbg,
+                               dwm, d.n, d.H, d.Hp, d.V, d.vid);
+        }
+    }
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}

@@ -1,0 +1,284 @@
+// HBM/L2-bound kernels of the chain passes: CSR gather-sum, row scatter, GRU and
+// gate/mapper pointwise parts (forward and backward), segmented column sums.
+// All rows are padded to a multiple of 32 floats, so every access is a 16-byte
+// float4 per lane, coalesced along the feature dimension.
+#include "common.h"
+#include "dvae_hip.h"
+
+namespace dvae {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---------------------------------------------------------------------------
+__global__ void gather_sum_kernel(float* __restrict__ out, int ld_out, const float* __restrict__ src, int ld_src,
+                                  const int* __restrict__ off, const int* __restrict__ idx, int rows, int w4,
+                                  int accumulate) {
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        int k0 = off[r], k1 = off[r + 1];
+        float4 acc = accumulate ? ld4(out + (long)r * ld_out + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = k0;
+        // two rows in flight per step
+        for (; k + 1 < k1; k += 2) {
+            float4 a = ld4(src + (long)idx[k] * ld_src + c);
+            float4 b = ld4(src + (long)idx[k + 1] * ld_src + c);
+            acc = add4(acc, a);
+            acc = add4(acc, b);
+        }
+        if (k < k1) acc = add4(acc, ld4(src + (long)idx[k] * ld_src + c));
+        st4(out + (long)r * ld_out + c, acc);
+    }
+}
+
+__global__ void scatter_rows_add_kernel(float* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src,
+                                        const int* __restrict__ off, const int* __restrict__ idx, int rows, int w4) {
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        float4 v = ld4(src + (long)r * ld_src + c);
+        for (int k = off[r]; k < off[r + 1]; ++k) {
+            float* d = dst + (long)idx[k] * ld_dst + c;
+            st4(d, add4(ld4(d), v));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__ gi_tab, const int* __restrict__ types,
+                               const float* __restrict__ bhn, const float* __restrict__ hprev, int ld_hprev,
+                               float* __restrict__ hout, int ld_hout, float* __restrict__ ghn_out, int rows, int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        float* g = gh + (long)r * 3 * Hp;
+        const float* gi = gi_tab + (long)types[r] * 3 * Hp;
+        float4 ghr = ld4(g + c), ghz = ld4(g + Hp + c), ghn = ld4(g + 2 * Hp + c);
+        float4 gir = ld4(gi + c), giz = ld4(gi + Hp + c), gin = ld4(gi + 2 * Hp + c);
+        float4 bn = ld4(bhn + c);
+        float4 hp = hprev ? ld4(hprev + (long)r * ld_hprev + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 R, Z, N, Hn, GN;
+#define GRU1(f)                                        \
+    {                                                  \
+        float gn = ghn.f + bn.f;                       \
+        float rr = 1.f / (1.f + expf(-(gir.f + ghr.f))); \
+        float zz = 1.f / (1.f + expf(-(giz.f + ghz.f))); \
+        float nn = tanhf(gin.f + rr * gn);             \
+        R.f = rr; Z.f = zz; N.f = nn; GN.f = gn;       \
+        Hn.f = (1.f - zz) * nn + zz * hp.f;            \
+    }
+        GRU1(x) GRU1(y) GRU1(z) GRU1(w)
+#undef GRU1
+        st4(g + c, R);
+        st4(g + Hp + c, Z);
+        st4(g + 2 * Hp + c, N);
+        st4(ghn_out + (long)r * Hp + c, GN);
+        st4(hout + (long)r * ld_hout + c, Hn);
+    }
+}
+
+__global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const float* __restrict__ gates,
+                               const float* __restrict__ ghn, const float* __restrict__ hprev, int ld_hprev,
+                               float* __restrict__ dgh, float* __restrict__ dgin, float* __restrict__ dhprev,
+                               int ld_dhprev, int rows, int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        const float* g = gates + (long)r * 3 * Hp;
+        float4 R = ld4(g + c), Z = ld4(g + Hp + c), N = ld4(g + 2 * Hp + c);
+        float4 GN = ld4(ghn + (long)r * Hp + c);
+        float4 D = ld4(dh + (long)r * ld_dh + c);
+        float4 hp = hprev ? ld4(hprev + (long)r * ld_hprev + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dR, dZ, dGN, dPN, dHP;
+#define GRUB(f)                                      \
+    {                                                \
+        float d = D.f;                               \
+        float dn = d * (1.f - Z.f);                  \
+        float dz = d * (hp.f - N.f);                 \
+        float dpn = dn * (1.f - N.f * N.f);          \
+        float dr = dpn * GN.f;                       \
+        dGN.f = dpn * R.f;                           \
+        dPN.f = dpn;                                 \
+        dR.f = dr * R.f * (1.f - R.f);               \
+        dZ.f = dz * Z.f * (1.f - Z.f);               \
+        dHP.f = d * Z.f;                             \
+    }
+        GRUB(x) GRUB(y) GRUB(z) GRUB(w)
+#undef GRUB
+        float* o = dgh + (long)r * 3 * Hp;
+        st4(o + c, dR);
+        st4(o + Hp + c, dZ);
+        st4(o + 2 * Hp + c, dGN);
+        st4(dgin + (long)r * Hp + c, dPN);
+        if (dhprev) st4(dhprev + (long)r * ld_dhprev + c, dHP);
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void gated_fwd_kernel(float* __restrict__ gm, const float* __restrict__ gv, float* __restrict__ msg,
+                                 int ld_msg, int rows, int Hp, int row_base, int rows_per_level) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        int lvl = (row_base + r) / rows_per_level;
+        float* p = gm + (long)r * 2 * Hp;
+        const float* v = gv + (long)lvl * 2 * Hp;
+        float4 a = add4(ld4(p + c), ld4(v + c));
+        float4 m = add4(ld4(p + Hp + c), ld4(v + Hp + c));
+        float4 g = make_float4(1.f / (1.f + expf(-a.x)), 1.f / (1.f + expf(-a.y)), 1.f / (1.f + expf(-a.z)),
+                               1.f / (1.f + expf(-a.w)));
+        st4(p + c, g);
+        st4(p + Hp + c, m);
+        st4(msg + (long)r * ld_msg + c, make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w));
+    }
+}
+
+__global__ void gated_bwd_kernel(const float* __restrict__ dmsg, int ld_dmsg, const float* __restrict__ gm,
+                                 float* __restrict__ dgm, int rows, int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        const float* p = gm + (long)r * 2 * Hp;
+        float4 g = ld4(p + c), m = ld4(p + Hp + c), d = ld4(dmsg + (long)r * ld_dmsg + c);
+        float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                                d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
+        float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        float* o = dgm + (long)r * 2 * Hp;
+        st4(o + c, dg);
+        st4(o + Hp + c, dm);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// out[seg][c] += sum_{rows of seg} x[row][c].  grid: (width/4/64, chunks, segs)
+__global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__ out, int ld_out,
+                                                             const float* __restrict__ x, int ld_x, int rows,
+                                                             int seg_rows, int w4, int rows_per_chunk) {
+    __shared__ float4 red[4][64];
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int c4 = blockIdx.x * 64 + tx;
+    int seg = blockIdx.z;
+    int r0 = seg * seg_rows + blockIdx.y * rows_per_chunk;
+    int r1 = min(min(r0 + rows_per_chunk, (seg + 1) * seg_rows), rows);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < w4) {
+        for (int r = r0 + ty; r < r1; r += 4) acc = add4(acc, ld4(x + (long)r * ld_x + c4 * 4));
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c4 < w4) {
+        acc = add4(add4(red[0][tx], red[1][tx]), add4(red[2][tx], red[3][tx]));
+        float* o = out + (long)seg * ld_out + c4 * 4;
+        atomicAdd(o + 0, acc.x);
+        atomicAdd(o + 1, acc.y);
+        atomicAdd(o + 2, acc.z);
+        atomicAdd(o + 3, acc.w);
+    }
+}
+
+static inline int ew_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" int dvae_gather_sum_f32(float* out, int32_t ld_out, const float* src, int32_t ld_src, const int32_t* off,
+                                   const int32_t* idx, int32_t rows, int32_t width, int32_t accumulate, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(out && src && off, "gather_sum: null pointer");
+    DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_out % 4 == 0 && ld_src % 4 == 0, "gather_sum: width/ld must be multiples of 4");
+    long total = (long)rows * (width / 4);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, out, ld_out, src,
+                       ld_src, off, idx, rows, width / 4, accumulate);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_scatter_rows_add_f32(float* dst, int32_t ld_dst, const float* src, int32_t ld_src,
+                                         const int32_t* off, const int32_t* idx, int32_t rows, int32_t width,
+                                         void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(dst && src && off, "scatter_rows_add: null pointer");
+    DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0, "scatter_rows_add: width/ld must be multiples of 4");
+    long total = (long)rows * (width / 4);
+    hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst,
+                       src, ld_src, off, idx, rows, width / 4);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int32_t* types, const float* bhn,
+                                      const float* hprev, int32_t ld_hprev, float* hout, int32_t ld_hout,
+                                      float* ghn_out, int32_t rows, int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(gh && gi_tab && types && bhn && hout && ghn_out, "gru_pointwise_fwd: null pointer");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_hout % 4 == 0 && (!hprev || ld_hprev % 4 == 0), "gru_pointwise_fwd: bad Hp/ld");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gh, gi_tab, types, bhn,
+                       hprev, ld_hprev, hout, ld_hout, ghn_out, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const float* gates, const float* ghn,
+                                      const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,
+                                      int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(dh && gates && ghn && dgh && dgin, "gru_pointwise_bwd: null pointer");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_dh % 4 == 0, "gru_pointwise_bwd: bad Hp/ld");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dh, ld_dh, gates, ghn,
+                       hprev, ld_hprev, dgh, dgin, dhprev, ld_dhprev, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gated_pointwise_fwd(float* gm, const float* gv, float* msg, int32_t ld_msg, int32_t rows,
+                                        int32_t Hp, int32_t row_base, int32_t rows_per_level, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(gm && gv && msg, "gated_pointwise_fwd: null pointer");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_msg % 4 == 0 && rows_per_level > 0, "gated_pointwise_fwd: bad size");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gm, gv, msg, ld_msg,
+                       rows, Hp, row_base, rows_per_level);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, const float* gm, float* dgm, int32_t rows,
+                                        int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(dmsg && gm && dgm, "gated_pointwise_bwd: null pointer");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_dmsg % 4 == 0, "gated_pointwise_bwd: bad size");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gated_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dmsg, ld_dmsg, gm,
+                       dgm, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
+                                       int32_t seg_rows, int32_t width, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(out && x, "segment_colsum: null pointer");
+    DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_x % 4 == 0 && seg_rows > 0, "segment_colsum: bad size");
+    int segs = cdiv(rows, seg_rows);
+    int w4 = width / 4;
+    int chunks = cdiv(seg_rows, 256);
+    if (chunks > 64) chunks = 64;
+    int rpc = cdiv(seg_rows, chunks);
+    chunks = cdiv(seg_rows, rpc);
+    hipLaunchKernelGGL(segment_colsum_kernel, dim3(cdiv(w4, 64), chunks, segs), dim3(256), 0, (hipStream_t)stream, out,
+                       ld_out, x, ld_x, rows, seg_rows, w4, rpc);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}

@@ -1,0 +1,582 @@
+// Orchestration of the D-VAE train-step hot path on one GPU:
+//   dvae_encode_forward / _backward   models.py:720-731 (BN :1068-1080) and its autograd
+//   dvae_loss_forward  / _backward    models.py:806-860 and its autograd
+// Every function only enqueues kernels on the caller's stream, works out of a
+// caller-provided workspace (sizes from dvae_*_ws_floats) and never allocates.
+//
+// Level-batched evaluation: level == vertex index,
+// slot(v, b) = v*B + b, all per-vertex tensors are [n*B][..] level-major so a level
+// is a contiguous row range.  Dependent kernel launches on one stream are the
+// level barrier (cheaper on MI355X than an in-kernel grid barrier: ~1.5 us vs
+// ~4-7 us, MI355X_MICROARCH.md price list rows `boundary` / `barrier-xcd`).
+#include "common.h"
+#include "model.h"
+#include "batch.h"
+
+namespace dvae {
+
+// ------------------------------------------------------------------ small kernels
+__global__ void onehot_kernel(float* x, const int* types, int rows, int Tp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Tp) return;
+    int r = i / Tp, t = i % Tp;
+    x[i] = types[r] == t ? 1.f : 0.f;
+}
+// cnt[r][t] = number of list entries of row r equal to t
+__global__ void count_kernel(float* cnt, const int* off, const int* idx, int rows, int Tp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Tp) return;
+    int r = i / Tp, t = i % Tp;
+    int c = 0;
+    for (int k = off[r]; k < off[r + 1]; ++k) c += idx[k] == t;
+    cnt[i] = (float)c;
+}
+// out12 [B][2NZp] -> mu, logvar [B][nz]
+__global__ void split_mu_logvar_kernel(const float* out12, float* mu, float* logvar, int B, int nz, int NZp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nz) return;
+    int b = i / nz, j = i % nz;
+    mu[i] = out12[(long)b * 2 * NZp + j];
+    logvar[i] = out12[(long)b * 2 * NZp + NZp + j];
+}
+__global__ void join_mu_logvar_kernel(float* d12, const float* dmu, const float* dlogvar, int B, int nz, int NZp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * NZp) return;
+    int b = i / (2 * NZp), c = i % (2 * NZp);
+    float v = 0.f;
+    if (c < nz) v = dmu[b * nz + c];
+    else if (c >= NZp && c < NZp + nz) v = dlogvar[b * nz + (c - NZp)];
+    d12[i] = v;
+}
+// d *= (1 - y^2)
+__global__ void tanh_bwd_kernel(float* d, const float* y, long n) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) d[i] *= (1.f - y[i] * y[i]);
+}
+__global__ void add_inplace_kernel(float* d, const float* a, long n) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) d[i] += a[i];
+}
+// d = y > 0 ? d : 0
+__global__ void relu_bwd_kernel(float* d, const float* y, long n) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) d[i] = y[i] > 0.f ? d[i] : 0.f;
+}
+__global__ void scaled_copy_kernel(float* d, const float* x, const float* s, long n) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) d[i] = x[i] * s[0];
+}
+// sums = {pair loss, ce loss, kld, -} -> out3 = {res + beta kld, res, kld}
+__global__ void finalize_loss_kernel(const float* sums, float beta, float* out3) {
+    float res = sums[0] + sums[1];
+    out3[0] = res + beta * sums[2];
+    out3[1] = res;
+    out3[2] = sums[2];
+}
+// g3 = upstream grads of (loss, res, kld) -> gs = {d/d res, d/d kld}
+__global__ void grad_scales_kernel(const float* g3, float beta, float* gs) {
+    gs[0] = g3[0] + g3[1];
+    gs[1] = beta * g3[0] + g3[2];
+}
+// *out = scale * sum(x[0:n])
+__global__ void sum_scaled_kernel(const float* x, int n, const float* scale, float* out) {
+    float v = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += x[i];
+    v = wave_sum(v);
+    __shared__ float red[4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale[0]);
+}
+
+#define EW(kern, total, ...)                                                                             \
+    do {                                                                                                 \
+        long t__ = (total);                                                                              \
+        if (t__ > 0) {                                                                                   \
+            hipLaunchKernelGGL(kern, dim3(cdiv(t__, 256)), dim3(256), 0, s, __VA_ARGS__);                \
+            DVAE_LAUNCH_CHECK();                                                                         \
+        }                                                                                                \
+    } while (0)
+
+// ------------------------------------------------------------------ gemm shorthands
+// Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
+static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
+                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s) {
+    dvae_gemm_desc g = {};
+    g.A = X; g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc;
+    return gemm(g, s);
+}
+// dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)
+static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
+                     int N, int K, int acc, hipStream_t s) {
+    dvae_gemm_desc g = {};
+    g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
+    g.M = M; g.N = K; g.K = N; g.accumulate = acc;
+    return gemm(g, s);
+}
+// dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
+static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
+                     int N, int K, hipStream_t s) {
+    dvae_gemm_desc g = {};
+    g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
+    g.M = N; g.N = K; g.K = M; g.accumulate = 1;
+    return gemm(g, s);
+}
+
+// ------------------------------------------------------------------ workspaces
+struct Bump {
+    float* base;
+    size_t off;
+    float* take(size_t n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~(size_t)63;
+        return p;
+    }
+};
+
+struct EncWs {
+    float *agg[2], *gates[2], *ghn[2], *hs[2], *gm[2], *msg[2];
+    float *hg, *hgu, *out12;
+    float* xoh;  // one-hot of vertex types [nB][Tp]
+    // backward
+    float *dhs[2], *dmsg, *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt;
+    float *d12, *dhgu, *dhg;
+    size_t total;
+};
+static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
+    EncWs w;
+    Bump b{base, 0};
+    const size_t nB = c.nB, Hp = d.Hp;
+    const int dirs = d.bidir ? 2 : 1;
+    for (int k = 0; k < 2; ++k) {
+        bool on = k < dirs;
+        w.agg[k] = on ? b.take(nB * Hp) : nullptr;
+        w.gates[k] = on ? b.take(nB * 3 * Hp) : nullptr;
+        w.ghn[k] = on ? b.take(nB * Hp) : nullptr;
+        w.hs[k] = on ? b.take(nB * Hp) : nullptr;
+        w.gm[k] = (on && !d.bn) ? b.take(nB * 2 * Hp) : nullptr;
+        w.msg[k] = (on && !d.bn) ? b.take(nB * Hp) : nullptr;
+    }
+    w.hg = b.take((size_t)c.B * 2 * Hp);
+    w.hgu = b.take((size_t)c.B * Hp);
+    w.out12 = b.take((size_t)c.B * 2 * d.NZp);
+    w.xoh = b.take(nB * d.Tp);
+    for (int k = 0; k < 2; ++k) {
+        bool on = k < dirs;
+        w.dhs[k] = on ? b.take(nB * Hp) : nullptr;
+        w.dgm[k] = (on && !d.bn) ? b.take(nB * 2 * Hp) : nullptr;
+        w.dgh[k] = on ? b.take(nB * 3 * Hp) : nullptr;
+        w.dgin[k] = on ? b.take(nB * Hp) : nullptr;
+        w.dagg[k] = on ? b.take(nB * Hp) : nullptr;
+    }
+    w.dmsg = d.bn ? nullptr : b.take((size_t)c.B * Hp);
+    w.cnt = d.bn ? b.take(nB * d.Tp) : nullptr;
+    w.d12 = b.take((size_t)c.B * 2 * d.NZp);
+    w.dhgu = b.take((size_t)c.B * Hp);
+    w.dhg = b.take((size_t)c.B * 2 * Hp);
+    w.total = b.off;
+    return w;
+}
+
+struct DecWs {
+    float *z, *agg, *gates, *ghn, *st, *gm, *msg;
+    float *ea, *eb, *ec, *dl, *vs, *v1, *logits, *dlogits, *sums, *xoh, *cnt;
+    // backward
+    float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dmsg, *dgm, *dh0c, *dz, *gs;
+    int dw2_blocks;
+    size_t total;
+};
+static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
+    DecWs w;
+    Bump b{base, 0};
+    const size_t nB = c.nB, Hp = d.Hp, NST = (size_t)c.nB + c.PT, HEp = d.HEp;
+    w.z = b.take((size_t)c.B * d.NZp);
+    w.agg = b.take(NST * Hp);
+    w.gates = b.take(NST * 3 * Hp);
+    w.ghn = b.take(NST * Hp);
+    w.st = b.take(NST * Hp);
+    w.gm = d.bn ? nullptr : b.take(nB * 2 * Hp);
+    w.msg = d.bn ? nullptr : b.take(nB * Hp);
+    w.ea = b.take((size_t)(c.NA + 1) * HEp);
+    w.eb = b.take((size_t)(c.NB + 1) * HEp);
+    w.ec = d.bn ? b.take((size_t)c.B * HEp) : nullptr;
+    w.dl = b.take(c.NP);
+    w.vs = b.take((size_t)c.R * Hp);
+    w.v1 = b.take((size_t)c.R * d.HVp);
+    w.logits = b.take((size_t)c.R * d.Tp);
+    w.dlogits = b.take((size_t)c.R * d.Tp);
+    w.sums = b.take(8);
+    w.xoh = b.take(NST * d.Tp);
+    w.cnt = d.bn ? b.take(NST * d.Tp) : nullptr;
+    w.dlogits_s = b.take((size_t)c.R * d.Tp);
+    w.dea = b.take((size_t)(c.NA + 1) * HEp);
+    w.deb = b.take((size_t)(c.NB + 1) * HEp);
+    w.dec = d.bn ? b.take((size_t)c.B * HEp) : nullptr;
+    w.dw2_blocks = 1024;
+    w.dw2p = b.take((size_t)w.dw2_blocks * HEp);
+    w.dst = b.take(NST * Hp);
+    w.dv1 = b.take((size_t)c.R * d.HVp);
+    w.dvs = b.take((size_t)c.R * Hp);
+    w.dgh = b.take(NST * 3 * Hp);
+    w.dgin = b.take(NST * Hp);
+    w.dagg = b.take(NST * Hp);
+    w.dmsg = d.bn ? nullptr : b.take((size_t)c.B * Hp);
+    w.dgm = d.bn ? nullptr : b.take(nB * 2 * Hp);
+    w.dh0c = d.bn ? b.take((size_t)c.B * Hp) : nullptr;
+    w.dz = b.take((size_t)c.B * d.NZp);
+    w.gs = b.take(8);
+    w.total = b.off;
+    return w;
+}
+
+static int check_batch(const Dims& d, const dvae_batch_counts* c) {
+    DVAE_REQUIRE(c != nullptr, "null batch counts");
+    DVAE_REQUIRE(c->n == d.n && c->T == d.T && (c->is_bn != 0) == (d.bn != 0),
+                 "batch was packed for a different model (max_n %d vs %d, nvt %d vs %d, bn %d vs %d)", c->n, d.n, c->T,
+                 d.T, c->is_bn, d.bn);
+    DVAE_REQUIRE(c->B > 0 && c->nB == c->n * c->B, "corrupt batch counts");
+    return DVAE_OK;
+}
+
+// weight gradients shared by every GRU pass: dWhh, d gi_tab, d bhn
+static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
+                      const float* agg, const float* xoh, int rows, hipStream_t s) {
+    const int Hp = d.Hp;
+    DVAE_TRY(lin_wgrad(dgh, 3 * Hp, agg, Hp, nullptr, pg + L.whh[g], Hp, rows, 3 * Hp, Hp, s));
+    // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin
+    DVAE_TRY(lin_wgrad(xoh, d.Tp, dgh, 3 * Hp, nullptr, pg + L.gi[g], 3 * Hp, rows, d.Tp, 2 * Hp, s));
+    DVAE_TRY(lin_wgrad(xoh, d.Tp, dgin, Hp, nullptr, pg + L.gi[g] + 2 * Hp, 3 * Hp, rows, d.Tp, Hp, s));
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bhn[g], Hp, dgh + 2 * Hp, 3 * Hp, rows, rows, Hp, s));
+    return DVAE_OK;
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" int64_t dvae_encode_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c) {
+    Dims d;
+    if (make_dims(m, d) != 0 || check_batch(d, c) != 0) return -1;
+    return (int64_t)carve_enc(d, *c, nullptr).total;
+}
+extern "C" int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c) {
+    Dims d;
+    if (make_dims(m, d) != 0 || check_batch(d, c) != 0) return -1;
+    return (int64_t)carve_dec(d, *c, nullptr).total;
+}
+
+// =====================================================================================
+// encode
+// =====================================================================================
+extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob,
+                                   const float* pw, float* ws, float* mu, float* logvar, void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_TRY(check_batch(d, c));
+    DVAE_REQUIRE(blob && pw && ws && mu && logvar, "dvae_encode_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const PackedLayout L = make_layout(d);
+    const BatchView bv = bind_batch(*c, blob);
+    EncWs w = carve_enc(d, *c, ws);
+    const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
+    const int dirs = d.bidir ? 2 : 1;
+
+    for (int k = 0; k < dirs; ++k) {
+        const int* off = k == 0 ? bv.pred_off : bv.succ_off;
+        const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+        const float* whh = pw + L.whh[k];
+        if (d.bn) {
+            DVAE_TRY(dvae_gather_sum_f32(w.agg[k], Hp, pw + L.gtab[k], Hp, off, idx, nB, Hp, 0, s));
+            DVAE_TRY(lin_fwd(w.agg[k], Hp, nullptr, whh, Hp, nullptr, w.gates[k], 3 * Hp, nB, 3 * Hp, Hp, 0, 0, s));
+            DVAE_TRY(dvae_gru_pointwise_fwd(w.gates[k], pw + L.gi[k], bv.types, pw + L.bhn[k], w.agg[k], Hp, w.hs[k],
+                                            Hp, w.ghn[k], nB, Hp, s));
+            continue;
+        }
+        for (int step = 0; step < n; ++step) {
+            const int v = k == 0 ? step : n - 1 - step;
+            const long r0 = (long)v * B;
+            float* agg = w.agg[k] + r0 * Hp;
+            float* gates = w.gates[k] + r0 * 3 * Hp;
+            DVAE_TRY(dvae_gather_sum_f32(agg, Hp, w.msg[k], Hp, off + r0, idx, B, Hp, 0, s));
+            if (step == 0) {
+                DVAE_HIP(hipMemsetAsync(gates, 0, sizeof(float) * (size_t)B * 3 * Hp, s));
+            } else {
+                DVAE_TRY(lin_fwd(agg, Hp, nullptr, whh, Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
+            }
+            DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp,
+                                            w.hs[k] + r0 * Hp, Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
+            if (step < n - 1) {
+                float* gm = w.gm[k] + r0 * 2 * Hp;
+                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+                DVAE_TRY(dvae_gated_pointwise_fwd(gm, pw + L.gv[k], w.msg[k] + r0 * Hp, Hp, B, Hp, (int)r0, B, s));
+            }
+        }
+    }
+    // graph state (models.py:704-718 / 1006-1027)
+    DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
+    const float* hgu = w.hg;
+    int ld_hgu = 2 * Hp;
+    if (d.bidir) {
+        DVAE_TRY(dvae_gather_sum_f32(w.hg + Hp, 2 * Hp, w.hs[1], Hp, bv.hgb_off, bv.hgb_idx, B, Hp, 0, s));
+        DVAE_TRY(lin_fwd(w.hg, 2 * Hp, nullptr, pw + L.wu, 2 * Hp, pw + L.bu, w.hgu, Hp, B, Hp, 2 * Hp, 0, 0, s));
+        hgu = w.hgu;
+        ld_hgu = Hp;
+    }
+    DVAE_TRY(lin_fwd(hgu, ld_hgu, nullptr, pw + L.fc12, Hp, pw + L.b12, w.out12, 2 * d.NZp, B, 2 * d.NZp, Hp, 0, 0, s));
+    EW(split_mu_logvar_kernel, (long)B * d.nz, w.out12, mu, logvar, B, d.nz, d.NZp);
+    return DVAE_OK;
+}
+
+extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob,
+                                    const float* pw, float* ws, const float* dmu, const float* dlogvar, float* pg,
+                                    void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_TRY(check_batch(d, c));
+    DVAE_REQUIRE(blob && pw && ws && dmu && dlogvar && pg, "dvae_encode_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const PackedLayout L = make_layout(d);
+    const BatchView bv = bind_batch(*c, blob);
+    EncWs w = carve_enc(d, *c, ws);
+    const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, NZ2 = 2 * d.NZp;
+    const int dirs = d.bidir ? 2 : 1;
+
+    DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
+    EW(join_mu_logvar_kernel, (long)B * NZ2, w.d12, dmu, dlogvar, B, d.nz, d.NZp);
+    const float* hgu = d.bidir ? w.hgu : w.hg;
+    const int ld_hgu = d.bidir ? Hp : 2 * Hp;
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.b12, NZ2, w.d12, NZ2, B, B, NZ2, s));
+    DVAE_TRY(lin_wgrad(w.d12, NZ2, hgu, ld_hgu, nullptr, pg + L.fc12, Hp, B, NZ2, Hp, s));
+    DVAE_TRY(lin_dgrad(w.d12, NZ2, pw + L.fc12, Hp, w.dhgu, Hp, nullptr, B, NZ2, Hp, 0, s));
+    const float* dhg = w.dhgu;
+    int ld_dhg = Hp;
+    if (d.bidir) {
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.bu, Hp, w.dhgu, Hp, B, B, Hp, s));
+        DVAE_TRY(lin_wgrad(w.dhgu, Hp, w.hg, 2 * Hp, nullptr, pg + L.wu, 2 * Hp, B, Hp, 2 * Hp, s));
+        DVAE_TRY(lin_dgrad(w.dhgu, Hp, pw + L.wu, 2 * Hp, w.dhg, 2 * Hp, nullptr, B, Hp, 2 * Hp, 0, s));
+        dhg = w.dhg;
+        ld_dhg = 2 * Hp;
+    }
+    EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
+
+    for (int k = 0; k < dirs; ++k) {
+        const float* whh = pw + L.whh[k];
+        DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
+        DVAE_TRY(dvae_scatter_rows_add_f32(w.dhs[k], Hp, dhg + (k ? Hp : 0), ld_dhg, k ? bv.hgb_off : bv.hgf_off,
+                                           k ? bv.hgb_idx : bv.hgf_idx, B, Hp, s));
+        if (d.bn) {
+            DVAE_TRY(dvae_gru_pointwise_bwd(w.dhs[k], Hp, w.gates[k], w.ghn[k], w.agg[k], Hp, w.dgh[k], w.dgin[k],
+                                            w.dagg[k], Hp, nB, Hp, s));
+            DVAE_TRY(lin_dgrad(w.dgh[k], 3 * Hp, whh, Hp, w.dagg[k], Hp, nullptr, nB, 3 * Hp, Hp, 1, s));
+            // d gtab[t] = sum over slots of (#neighbours of type t) * dagg[slot]
+            const int* off = k == 0 ? bv.pred_off : bv.succ_off;
+            const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+            EW(count_kernel, (long)nB * d.Tp, w.cnt, off, idx, nB, d.Tp);
+            DVAE_TRY(lin_wgrad(w.cnt, d.Tp, w.dagg[k], Hp, nullptr, pg + L.gtab[k], Hp, nB, d.Tp, Hp, s));
+        } else {
+            // transposed neighbour lists: messages of v went to its successors (fwd pass) / predecessors (bwd pass)
+            const int* toff = k == 0 ? bv.succ_off : bv.pred_off;
+            const int* tidx = k == 0 ? bv.succ_idx : bv.pred_idx;
+            DVAE_HIP(hipMemsetAsync(w.dgm[k], 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
+            for (int step = n - 1; step >= 0; --step) {
+                const int v = k == 0 ? step : n - 1 - step;
+                const long r0 = (long)v * B;
+                float* dhs = w.dhs[k] + r0 * Hp;
+                if (step < n - 1) {
+                    DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg[k], Hp, toff + r0, tidx, B, Hp, 0, s));
+                    DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg, Hp, w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
+                    DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+                }
+                DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp,
+                                                w.agg[k] + r0 * Hp, Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp,
+                                                w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
+                if (step > 0)
+                    DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
+            }
+            DVAE_TRY(lin_wgrad(w.dgm[k], 2 * Hp, w.hs[k], Hp, nullptr, pg + L.wgm[k], Hp, nB, 2 * Hp, Hp, s));
+            DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
+        }
+        DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s));
+    }
+    return DVAE_OK;
+}
+
+// =====================================================================================
+// loss (teacher-forced decoder)
+// =====================================================================================
+extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob,
+                                 const float* pw, float* ws, const float* mu, const float* logvar, const float* eps,
+                                 float eps_scale, int32_t training, float beta, float* out3, void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_TRY(check_batch(d, c));
+    DVAE_REQUIRE(blob && pw && ws && mu && logvar && out3, "dvae_loss_forward: null pointer");
+    DVAE_REQUIRE(!training || eps, "dvae_loss_forward: training mode needs the normal draw eps");
+    hipStream_t s = (hipStream_t)stream;
+    const PackedLayout L = make_layout(d);
+    const BatchView bv = bind_batch(*c, blob);
+    DecWs w = carve_dec(d, *c, ws);
+    const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp;
+    const float* whh = pw + L.whh[2];
+    const float* gi = pw + L.gi[2];
+    const float* bhn = pw + L.bhn[2];
+
+    DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
+    DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
+    // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
+    DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
+    DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
+    DVAE_TRY(dvae_gru_pointwise_fwd(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, s));
+    if (d.bn) {
+        // no recurrence: messages depend on predecessor types only (models.py:1044-1062)
+        const long r0 = B;
+        DVAE_TRY(dvae_gather_sum_f32(w.agg + r0 * Hp, Hp, pw + L.gtab[0], Hp, bv.pred_off + r0, bv.pred_idx, nB - B, Hp, 0, s));
+        DVAE_TRY(dvae_gather_sum_f32(w.agg + (long)nB * Hp, Hp, pw + L.gtab[0], Hp, bv.p_off, bv.p_idx, PT, Hp, 0, s));
+        const int rows = nB - B + PT;
+        DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, rows, 3 * Hp, Hp, 0, 0, s));
+        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
+                                        w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, nB - B, Hp, s));
+        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + (long)nB * 3 * Hp, gi, bv.p_type, bhn, w.agg + (long)nB * Hp, Hp,
+                                        w.st + (long)nB * Hp, Hp, w.ghn + (long)nB * Hp, PT, Hp, s));
+    } else {
+        for (int v = 0; v < n; ++v) {
+            const long r0 = (long)v * B;
+            if (v > 0) {
+                DVAE_TRY(dvae_gather_sum_f32(w.agg + r0 * Hp, Hp, w.msg, Hp, bv.pred_off + r0, bv.pred_idx, B, Hp, 0, s));
+                DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
+                DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
+                                                w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, B, Hp, s));
+            }
+            if (v < n - 1) {
+                float* gm = w.gm + r0 * 2 * Hp;
+                DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+                DVAE_TRY(dvae_gated_pointwise_fwd(gm, pw + L.gv[0], w.msg + r0 * Hp, Hp, B, Hp, (int)r0, B, s));
+            }
+        }
+        // partial states: non-recurrent, one batched pass
+        const long p0 = nB;
+        DVAE_TRY(dvae_gather_sum_f32(w.agg + p0 * Hp, Hp, w.msg, Hp, bv.p_off, bv.p_idx, PT, Hp, 0, s));
+        DVAE_TRY(lin_fwd(w.agg + p0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + p0 * 3 * Hp, 3 * Hp, PT, 3 * Hp, Hp, 0, 0, s));
+        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + p0 * 3 * Hp, gi, bv.p_type, bhn, w.agg + p0 * Hp, Hp, w.st + p0 * Hp,
+                                        Hp, w.ghn + p0 * Hp, PT, Hp, s));
+    }
+    // edge predictor: first layer split over its inputs
+    DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
+    DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s));
+    DVAE_HIP(hipMemsetAsync(w.ea + (size_t)c->NA * HEp, 0, sizeof(float) * HEp, s));
+    DVAE_HIP(hipMemsetAsync(w.eb + (size_t)c->NB * HEp, 0, sizeof(float) * HEp, s));
+    if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
+    DVAE_TRY(dvae_pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t,
+                               pw + L.be1, pw + L.we2, pw + L.be2, w.dl, w.sums + 0, c->NP, HEp, s));
+    // vertex-type predictor
+    DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
+    DVAE_TRY(lin_fwd(w.vs, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1, d.HVp, c->R, d.HVp, Hp, 1, 0, s));
+    DVAE_TRY(lin_fwd(w.v1, d.HVp, nullptr, pw + L.wv2, d.HVp, pw + L.bv2, w.logits, d.Tp, c->R, d.Tp, d.HVp, 0, 0, s));
+    DVAE_TRY(dvae_vertex_ce(w.logits, d.Tp, bv.ce_off, bv.ce_tgt, w.dlogits, w.sums + 1, c->R, d.T, d.Tp, s));
+    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, s, w.sums, beta, out3);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob,
+                                  const float* pw, float* ws, const float* mu, const float* logvar, const float* eps,
+                                  float eps_scale, int32_t training, float beta, const float* g3, float* dmu,
+                                  float* dlogvar, float* pg, void* stream) {
+    Dims d;
+    DVAE_TRY(make_dims(m, d));
+    DVAE_TRY(check_batch(d, c));
+    DVAE_REQUIRE(blob && pw && ws && mu && logvar && g3 && dmu && dlogvar && pg, "dvae_loss_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const PackedLayout L = make_layout(d);
+    const BatchView bv = bind_batch(*c, blob);
+    DecWs w = carve_dec(d, *c, ws);
+    const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp, NST = nB + PT;
+    const float* whh = pw + L.whh[2];
+
+    DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
+    hipLaunchKernelGGL(grad_scales_kernel, dim3(1), dim3(1), 0, s, g3, beta, w.gs);
+    const float* g_res = w.gs;
+    const float* g_kld = w.gs + 1;
+
+    // ---- edge predictor ------------------------------------------------------------
+    DVAE_HIP(hipMemsetAsync(w.dea, 0, sizeof(float) * (size_t)(c->NA + 1) * HEp, s));
+    DVAE_HIP(hipMemsetAsync(w.deb, 0, sizeof(float) * (size_t)(c->NB + 1) * HEp, s));
+    const int* pc = d.bn ? bv.pair_c : nullptr;
+    DVAE_TRY(dvae_pair_bce_bwd_grouped(w.ea, bv.ca_off, bv.ca_row, bv.ca_pairs, w.eb, bv.pair_h, w.ec, pc, pw + L.be1,
+                                       pw + L.we2, w.dl, g_res, w.dea, w.dw2p, c->CA, HEp, w.dw2_blocks, s));
+    DVAE_TRY(dvae_pair_bce_bwd_grouped(w.eb, bv.ch_off, bv.ch_row, bv.ch_pairs, w.ea, bv.pair_a, w.ec, pc, pw + L.be1,
+                                       pw + L.we2, w.dl, g_res, w.deb, nullptr, c->CH, HEp, w.dw2_blocks, s));
+    if (d.bn) {
+        DVAE_HIP(hipMemsetAsync(w.dec, 0, sizeof(float) * (size_t)B * HEp, s));
+        DVAE_TRY(dvae_pair_bce_bwd_grouped(w.ec, bv.cc_off, bv.cc_row, nullptr, w.ea, bv.pair_a, w.eb, bv.pair_h,
+                                           pw + L.be1, pw + L.we2, w.dl, g_res, w.dec, nullptr, c->CC, HEp,
+                                           w.dw2_blocks, s));
+    }
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s));
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s));
+    hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s, w.dl, c->NP, g_res, pg + L.be2);
+    DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s));
+    DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s));
+    DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
+    DVAE_TRY(lin_dgrad(w.dea, HEp, pw + L.w1a, Hp, w.dst, Hp, bv.rowsA, c->NA, HEp, Hp, 1, s));
+    DVAE_TRY(lin_dgrad(w.deb, HEp, pw + L.w1b, Hp, w.dst, Hp, bv.rowsB, c->NB, HEp, Hp, 1, s));
+    if (d.bn) {
+        DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s));
+        DVAE_TRY(lin_dgrad(w.dec, HEp, pw + L.w1c, Hp, w.dh0c, Hp, nullptr, B, HEp, Hp, 0, s));
+    }
+    // ---- vertex-type predictor -------------------------------------------------------
+    EW(scaled_copy_kernel, (long)c->R * d.Tp, w.dlogits_s, w.dlogits, g_res, (long)c->R * d.Tp);
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s));
+    DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s));
+    DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s));
+    EW(relu_bwd_kernel, (long)c->R * d.HVp, w.dv1, w.v1, (long)c->R * d.HVp);
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv1, d.HVp, w.dv1, d.HVp, c->R, c->R, d.HVp, s));
+    DVAE_TRY(lin_wgrad(w.dv1, d.HVp, w.vs, Hp, nullptr, pg + L.wv1, Hp, c->R, d.HVp, Hp, s));
+    DVAE_TRY(lin_dgrad(w.dv1, d.HVp, pw + L.wv1, Hp, w.dvs, Hp, nullptr, c->R, d.HVp, Hp, 0, s));
+    DVAE_TRY(dvae_gather_sum_f32(w.dst, Hp, w.dvs, Hp, bv.vst_off, bv.vst_idx, nB, Hp, 1, s));
+
+    // ---- states --------------------------------------------------------------------
+    EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
+    EW(onehot_kernel, (long)PT * d.Tp, w.xoh + (size_t)nB * d.Tp, bv.p_type, PT, d.Tp);
+    if (d.bn) {
+        DVAE_TRY(dvae_gru_pointwise_bwd(w.dst, Hp, w.gates, w.ghn, w.agg, Hp, w.dgh, w.dgin, w.dagg, Hp, NST, Hp, s));
+        DVAE_TRY(lin_dgrad(w.dgh, 3 * Hp, whh, Hp, w.dagg, Hp, nullptr, NST, 3 * Hp, Hp, 1, s));
+        // message-table gradient from every row whose h_prev was a table sum (all but level 0)
+        EW(count_kernel, (long)(nB - B) * d.Tp, w.cnt + (size_t)B * d.Tp, bv.pred_off + B, bv.pred_idx, nB - B, d.Tp);
+        EW(count_kernel, (long)PT * d.Tp, w.cnt + (size_t)nB * d.Tp, bv.p_off, bv.p_idx, PT, d.Tp);
+        DVAE_TRY(lin_wgrad(w.cnt + (size_t)B * d.Tp, d.Tp, w.dagg + (size_t)B * Hp, Hp, nullptr, pg + L.gtab[0], Hp,
+                           NST - B, d.Tp, Hp, s));
+        EW(add_inplace_kernel, (long)B * Hp, w.dagg, w.dh0c, (long)B * Hp);
+    } else {
+        const long p0 = nB;
+        DVAE_TRY(dvae_gru_pointwise_bwd(w.dst + p0 * Hp, Hp, w.gates + p0 * 3 * Hp, w.ghn + p0 * Hp, w.agg + p0 * Hp, Hp,
+                                        w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp, s));
+        DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
+        DVAE_HIP(hipMemsetAsync(w.dgm, 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
+        for (int v = n - 1; v >= 0; --v) {
+            const long r0 = (long)v * B;
+            float* dst = w.dst + r0 * Hp;
+            if (v < n - 1) {
+                DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, B, Hp, 0, s));
+                DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg + p0 * Hp, Hp, bv.pt_off + r0, bv.pt_idx, B, Hp, 1, s));
+                DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg, Hp, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B, Hp, s));
+                DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+            }
+            DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,
+                                            w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
+            DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
+        }
+        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB, 2 * Hp, Hp, s));
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
+    }
+    DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, s));
+    // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------
+    EW(tanh_bwd_kernel, (long)B * Hp, w.dagg, w.agg, (long)B * Hp);
+    DVAE_TRY(dvae_segment_colsum_f32(pg + L.b3, Hp, w.dagg, Hp, B, B, Hp, s));
+    DVAE_TRY(lin_wgrad(w.dagg, Hp, w.z, d.NZp, nullptr, pg + L.fc3, d.NZp, B, Hp, d.NZp, s));
+    DVAE_TRY(lin_dgrad(w.dagg, Hp, pw + L.fc3, d.NZp, w.dz, d.NZp, nullptr, B, Hp, d.NZp, 0, s));
+    DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
+    return DVAE_OK;
+}

@@ -1,0 +1,324 @@
+"""Drop-in `DVAE` / `DVAE_BN` modules whose encode / loss / backward run on
+hand-written gfx950 HIP kernels (libdvae_hip.so, C-ABI in include/dvae_hip.h).
+
+Mirrors the class API of the reference (`/root/reference/models.py`):
+  DVAE.__init__            models.py:537-604   same sub-modules, same order ->
+                                               identical state_dict and seeded init
+  DVAE_BN.__init__         models.py:980-1000
+  _collate_fn              models.py:631-632   (returns a packed DAGBatch)
+  encode                   models.py:720-731   (BN 1068-1080)
+  reparameterize           models.py:733-740
+  loss                     models.py:806-860
+  forward                  models.py:867-870
+  get_device               models.py:606-609
+
+There is no PyTorch/CPU fallback for the compute: without the HIP library and a
+HIP device, encode()/loss() raise.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .batching import DAGBatch, GraphArrays, graphs_to_arrays
+
+# state_dict order == C-ABI parameter order (include/dvae_hip.h, DVAE_NUM_PARAMS)
+PARAM_NAMES = [
+    "grue_forward.weight_ih", "grue_forward.weight_hh", "grue_forward.bias_ih", "grue_forward.bias_hh",
+    "grue_backward.weight_ih", "grue_backward.weight_hh", "grue_backward.bias_ih", "grue_backward.bias_hh",
+    "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+    "grud.weight_ih", "grud.weight_hh", "grud.bias_ih", "grud.bias_hh",
+    "fc3.weight", "fc3.bias",
+    "add_vertex.0.weight", "add_vertex.0.bias", "add_vertex.2.weight", "add_vertex.2.bias",
+    "add_edge.0.weight", "add_edge.0.bias", "add_edge.2.weight", "add_edge.2.bias",
+    "gate_forward.0.weight", "gate_forward.0.bias", "gate_backward.0.weight", "gate_backward.0.bias",
+    "mapper_forward.0.weight", "mapper_backward.0.weight",
+    "hv_unify.0.weight", "hv_unify.0.bias", "hg_unify.0.weight", "hg_unify.0.bias",
+]
+assert len(PARAM_NAMES) == _lib.NUM_PARAMS
+_IDX = {k: i for i, k in enumerate(PARAM_NAMES)}
+
+_ENC_FWD = ["grue_forward.weight_ih", "grue_forward.weight_hh", "grue_forward.bias_ih", "grue_forward.bias_hh",
+            "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+            "gate_forward.0.weight", "gate_forward.0.bias", "mapper_forward.0.weight"]
+_ENC_BWD = ["grue_backward.weight_ih", "grue_backward.weight_hh", "grue_backward.bias_ih", "grue_backward.bias_hh",
+            "gate_backward.0.weight", "gate_backward.0.bias", "mapper_backward.0.weight",
+            "hg_unify.0.weight", "hg_unify.0.bias"]
+_DEC = ["grud.weight_ih", "grud.weight_hh", "grud.bias_ih", "grud.bias_hh", "fc3.weight", "fc3.bias",
+        "add_vertex.0.weight", "add_vertex.0.bias", "add_vertex.2.weight", "add_vertex.2.bias",
+        "add_edge.0.weight", "add_edge.0.bias", "add_edge.2.weight", "add_edge.2.bias",
+        "gate_forward.0.weight", "gate_forward.0.bias", "mapper_forward.0.weight"]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.DvaeHipError(
+            "%s: parameters are on %s; the D-VAE hot path only runs on a HIP device "
+            "(move the model with .to('cuda')). There is no CPU fallback." % (what, t.device))
+
+
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, batch, *params):
+        lib = _lib.load()
+        dev = params[0].device
+        pw = model._packed_weights()
+        B = batch.B
+        n_ws = lib.dvae_encode_ws_floats(C.byref(model._desc), C.byref(batch.counts))
+        if n_ws < 0:
+            _lib.check(-1, "dvae_encode_ws_floats")
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        mu = torch.empty(B, model.nz, dtype=torch.float32, device=dev)
+        logvar = torch.empty(B, model.nz, dtype=torch.float32, device=dev)
+        _lib.check(lib.dvae_encode_forward(C.byref(model._desc), C.byref(batch.counts), batch.blob.data_ptr(),
+                                           pw.data_ptr(), ws.data_ptr(), mu.data_ptr(), logvar.data_ptr(), _stream()),
+                   "dvae_encode_forward")
+        ctx.model, ctx.batch, ctx.ws, ctx.pw = model, batch, ws, pw
+        ctx.n_params = len(params)
+        return mu, logvar
+
+    @staticmethod
+    def backward(ctx, dmu, dlogvar):
+        lib = _lib.load()
+        model, batch = ctx.model, ctx.batch
+        dev = ctx.ws.device
+        dmu = torch.zeros(batch.B, model.nz, device=dev) if dmu is None else dmu.contiguous().float()
+        dlogvar = torch.zeros(batch.B, model.nz, device=dev) if dlogvar is None else dlogvar.contiguous().float()
+        pg = torch.empty(model._n_packed, dtype=torch.float32, device=dev)
+        _lib.check(lib.dvae_encode_backward(C.byref(model._desc), C.byref(batch.counts), batch.blob.data_ptr(),
+                                            ctx.pw.data_ptr(), ctx.ws.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(),
+                                            pg.data_ptr(), _stream()), "dvae_encode_backward")
+        grads = model._unpack(ctx.pw, pg, model._enc_names)
+        return (None, None) + tuple(grads)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, batch, eps, eps_scale, training, beta, mu, logvar, *params):
+        lib = _lib.load()
+        dev = params[0].device
+        pw = model._packed_weights()
+        mu_c, lv_c = mu.contiguous().float(), logvar.contiguous().float()
+        n_ws = lib.dvae_loss_ws_floats(C.byref(model._desc), C.byref(batch.counts))
+        if n_ws < 0:
+            _lib.check(-1, "dvae_loss_ws_floats")
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.dvae_loss_forward(C.byref(model._desc), C.byref(batch.counts), batch.blob.data_ptr(),
+                                         pw.data_ptr(), ws.data_ptr(), mu_c.data_ptr(), lv_c.data_ptr(),
+                                         eps.data_ptr() if eps is not None else None, float(eps_scale), int(training),
+                                         float(beta), out3.data_ptr(), _stream()), "dvae_loss_forward")
+        ctx.model, ctx.batch, ctx.ws, ctx.pw = model, batch, ws, pw
+        ctx.args = (mu_c, lv_c, eps, float(eps_scale), int(training), float(beta))
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        lib = _lib.load()
+        model, batch = ctx.model, ctx.batch
+        mu_c, lv_c, eps, eps_scale, training, beta = ctx.args
+        dev = ctx.ws.device
+        g3 = g3.contiguous().float()
+        pg = torch.empty(model._n_packed, dtype=torch.float32, device=dev)
+        dmu = torch.empty_like(mu_c)
+        dlogvar = torch.empty_like(lv_c)
+        _lib.check(lib.dvae_loss_backward(C.byref(model._desc), C.byref(batch.counts), batch.blob.data_ptr(),
+                                          ctx.pw.data_ptr(), ctx.ws.data_ptr(), mu_c.data_ptr(), lv_c.data_ptr(),
+                                          eps.data_ptr() if eps is not None else None, eps_scale, training, beta,
+                                          g3.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(), pg.data_ptr(), _stream()),
+                   "dvae_loss_backward")
+        grads = model._unpack(ctx.pw, pg, model._dec_names)
+        return (None, None, None, None, None, None, dmu, dlogvar) + tuple(grads)
+
+
+class DVAE(nn.Module):
+    """DAG variational autoencoder (reference `models.py:536-875`)."""
+    _is_bn = False
+
+    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False, vid=True):
+        super(DVAE, self).__init__()
+        self.max_n = max_n
+        self.nvt = nvt
+        self.START_TYPE = START_TYPE
+        self.END_TYPE = END_TYPE
+        self.hs = hs
+        self.nz = nz
+        self.gs = hs
+        self.bidir = bidirectional
+        self.vid = vid
+        self.device = None
+        self.vs = hs + max_n if self.vid else hs
+
+        # same construction order as the reference (identical RNG consumption)
+        self.grue_forward = nn.GRUCell(nvt, hs)
+        self.grue_backward = nn.GRUCell(nvt, hs)
+        self.fc1 = nn.Linear(self.gs, nz)
+        self.fc2 = nn.Linear(self.gs, nz)
+        self.grud = nn.GRUCell(nvt, hs)
+        self.fc3 = nn.Linear(nz, hs)
+        self.add_vertex = nn.Sequential(nn.Linear(hs, hs * 2), nn.ReLU(), nn.Linear(hs * 2, nvt))
+        self.add_edge = nn.Sequential(nn.Linear(hs * 2, hs * 4), nn.ReLU(), nn.Linear(hs * 4, 1))
+        self.gate_forward = nn.Sequential(nn.Linear(self.vs, hs), nn.Sigmoid())
+        self.gate_backward = nn.Sequential(nn.Linear(self.vs, hs), nn.Sigmoid())
+        self.mapper_forward = nn.Sequential(nn.Linear(self.vs, hs, bias=False))
+        self.mapper_backward = nn.Sequential(nn.Linear(self.vs, hs, bias=False))
+        if self.bidir:
+            self.hv_unify = nn.Sequential(nn.Linear(hs * 2, hs))
+            self.hg_unify = nn.Sequential(nn.Linear(self.gs * 2, self.gs))
+        self.relu = nn.ReLU()
+        self.sigmoid = nn.Sigmoid()
+        self.tanh = nn.Tanh()
+        self.logsoftmax1 = nn.LogSoftmax(1)
+        self._finish_init()
+
+    # ------------------------------------------------------------------ plumbing
+    def _finish_init(self):
+        self._desc = _lib.ModelDesc(self.max_n, self.nvt, self.hs, self.nz, int(bool(self.bidir)),
+                                    int(bool(self.vid) and not self._is_bn), int(self._is_bn),
+                                    int(self.START_TYPE), int(self.END_TYPE))
+        if self.max_n > 64 or self.max_n < 2:
+            raise ValueError("max_n must be in 2..64")
+        if self.nvt > 32:
+            raise ValueError("nvt must be <= 32")
+        self._n_packed = None
+        self._pw = None
+        self._pw_key = None
+        self._enc_names = _ENC_FWD + (_ENC_BWD if self.bidir else [])
+        self._dec_names = list(_DEC)
+        self.eps_override = None  # test hook: fixed normal draw for reparameterize
+
+    def _param_table(self):
+        named = dict(self.named_parameters())
+        return [named.get(k) for k in PARAM_NAMES]
+
+    def _hot_params(self, names):
+        named = dict(self.named_parameters())
+        return [named[k] for k in names]
+
+    def _packed_weights(self):
+        """Zero-padded device copy of the weights, rebuilt when any parameter
+        changed (optimizer steps bump tensor versions)."""
+        lib = _lib.load()
+        table = self._param_table()
+        first = next(p for p in table if p is not None)
+        _require_gpu(first, "DVAE")
+        key = tuple((p.data_ptr(), p._version) if p is not None else None for p in table)
+        if self._pw is not None and key == self._pw_key and self._pw.device == first.device:
+            return self._pw
+        if self._n_packed is None:
+            self._n_packed = int(lib.dvae_packed_floats(C.byref(self._desc)))
+            if self._n_packed < 0:
+                _lib.check(-1, "dvae_packed_floats")
+        for p in table:
+            if p is not None and (p.dtype != torch.float32 or not p.is_contiguous()):
+                raise _lib.DvaeHipError("parameters must be contiguous float32")
+        arr = (C.c_void_p * _lib.NUM_PARAMS)(*[p.data_ptr() if p is not None else None for p in table])
+        pw = torch.empty(self._n_packed, dtype=torch.float32, device=first.device)
+        _lib.check(lib.dvae_pack_weights(C.byref(self._desc), arr, pw.data_ptr(), _stream()), "dvae_pack_weights")
+        self._pw, self._pw_key = pw, key
+        return pw
+
+    def _unpack(self, pw, pg, names):
+        lib = _lib.load()
+        named = dict(self.named_parameters())
+        ptrs = [None] * _lib.NUM_PARAMS
+        want = [0] * _lib.NUM_PARAMS
+        grads = []
+        for k in names:
+            g = torch.empty_like(named[k])
+            grads.append(g)
+            ptrs[_IDX[k]] = g.data_ptr()
+            want[_IDX[k]] = 1
+        arr = (C.c_void_p * _lib.NUM_PARAMS)(*ptrs)
+        w = (C.c_uint8 * _lib.NUM_PARAMS)(*want)
+        _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), arr, w, _stream()),
+                   "dvae_unpack_grads")
+        return grads
+
+    def _as_batch(self, G):
+        if isinstance(G, DAGBatch):
+            return G
+        if not isinstance(G, (list, tuple, GraphArrays)):
+            G = [G]  # single graph, as models.py:722-723
+        arrays = graphs_to_arrays(G, self.max_n)
+        return DAGBatch(arrays, self.nvt, self.START_TYPE, self._is_bn, self.get_device())
+
+    # ------------------------------------------------------------------ reference API
+    def get_device(self):
+        if self.device is None:
+            self.device = next(self.parameters()).device
+        return self.device
+
+    def _apply(self, fn, *a, **kw):
+        self.device = None
+        self._pw = None
+        return super(DVAE, self)._apply(fn, *a, **kw)
+
+    def _collate_fn(self, G):
+        """Packs the batch once; encode() and loss() both accept the result."""
+        return self._as_batch(G)
+
+    def encode(self, G):
+        batch = self._as_batch(G)
+        params = self._hot_params(self._enc_names)
+        return _EncodeFn.apply(self, batch, *params)
+
+    def reparameterize(self, mu, logvar, eps_scale=0.01):
+        if self.training:
+            std = logvar.mul(0.5).exp_()
+            eps = torch.randn_like(std) * eps_scale
+            return eps.mul(std).add_(mu)
+        return mu
+
+    def loss(self, mu, logvar, G_true, beta=0.005, eps=None):
+        """(res + beta*kld, res, kld).  `eps` optionally injects the standard-normal
+        draw of reparameterize (shape [B, nz]); default: torch.randn on the device."""
+        batch = self._as_batch(G_true)
+        if mu.shape[0] != batch.B:
+            raise ValueError("mu has %d rows, batch has %d graphs" % (mu.shape[0], batch.B))
+        if eps is None:
+            eps = self.eps_override
+        if self.training:
+            if eps is None:
+                eps = torch.randn(batch.B, self.nz, device=mu.device, dtype=torch.float32)
+            eps = eps.to(device=mu.device, dtype=torch.float32).contiguous()
+        else:
+            eps = None
+        params = self._hot_params(self._dec_names)
+        out3 = _LossFn.apply(self, batch, eps, 0.01, self.training, beta, mu, logvar, *params)
+        return out3[0], out3[1], out3[2]
+
+    def forward(self, G):
+        batch = self._as_batch(G)
+        mu, logvar = self.encode(batch)
+        loss, _, _ = self.loss(mu, logvar, batch)
+        return loss
+
+    def decode(self, z, stochastic=True):
+        raise NotImplementedError("decode() is outside the train-step hot path (SURVEY.md 8f row N1)")
+
+    def encode_decode(self, G):
+        raise NotImplementedError("encode_decode() is outside the train-step hot path (SURVEY.md 8f row N1)")
+
+    def generate_sample(self, n):
+        raise NotImplementedError("generate_sample() is outside the train-step hot path (SURVEY.md 8f row N1)")
+
+
+class DVAE_BN(DVAE):
+    """D-VAE for Bayesian networks (reference `models.py:979-1085`)."""
+    _is_bn = True
+
+    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False):
+        super(DVAE_BN, self).__init__(max_n, nvt, START_TYPE, END_TYPE, hs, nz, bidirectional)
+        # re-created after the base constructor, in the reference's order (extra RNG draws)
+        self.mapper_forward = nn.Sequential(nn.Linear(self.nvt, hs, bias=False))
+        self.mapper_backward = nn.Sequential(nn.Linear(self.nvt, hs, bias=False))
+        self.gate_forward = nn.Sequential(nn.Linear(self.nvt, hs), nn.Sigmoid())
+        self.gate_backward = nn.Sequential(nn.Linear(self.nvt, hs), nn.Sigmoid())
+        self.add_edge = nn.Sequential(nn.Linear(hs * 3, hs), nn.ReLU(), nn.Linear(hs, 1))
+        self._finish_init()

@@ -1,0 +1,218 @@
+/* C-ABI of libdvae_hip.so -- the MI355X (gfx950) implementation of the D-VAE
+ * train-step hot path (encode -> teacher-forced loss -> backward).
+ *
+ * The reference (muhanzhang/D-VAE) is pure Python/PyTorch and has NO FFI or
+ * plugin interface for this path: its boundary is the
+ * Python class API models.DVAE / models.DVAE_BN.  This C-ABI therefore sits
+ * BELOW that boundary; each entry point cites the reference code it replaces.
+ * The Python host mirror (d-vae_amd/models.py) keeps the reference's class API
+ * and calls these through ctypes.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All `float*` / `int32_t*`
+ *     arguments are DEVICE pointers unless a comment says "host".
+ *   - every function returns 0 on success or a negative code and records a
+ *     message retrievable with dvae_last_error() (thread-local).
+ *   - functions taking `void* stream` (a hipStream_t) only enqueue work on that
+ *     stream; they never allocate, never synchronise the device.
+ *   - all arithmetic is fp32 (MFMA v_mfma_f32_32x32x2_f32 for contractions).
+ *   - feature dimensions are zero-padded to multiples of 32 ("Hp" = padded hs).
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* dvae_last_error(void);
+int dvae_version(void);
+
+/* ---------------------------------------------------------------------------
+ * Building blocks (exported so that tests can check each kernel on its own)
+ * ------------------------------------------------------------------------- */
+
+/* C[MxN] (+)= act(A'[MxK] B'[KxN] + bias).  Replaces the torch.nn.Linear /
+ * addmm call sites of the path: models.py:629 (gate, mapper), :670 (GRUCell
+ * hidden product), :745 (add_edge), :823 (add_vertex), :730 (fc1, fc2), :810
+ * (fc3), and their autograd backward products.
+ * a_kmajor / b_kmajor = 0: operand stored [rows][K] (K contiguous);
+ *                     = 1: operand stored [K][rows].
+ * a_rows/b_rows (nullable) gather rows of the stored matrix; c_rows (nullable)
+ * scatters output rows (indices must be unique when accumulate = 1).
+ * act: 0 none, 1 relu, 2 tanh. */
+typedef struct dvae_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    const int32_t* a_rows;
+    const int32_t* b_rows;
+    const int32_t* c_rows;
+    const float* bias;
+    int32_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t a_kmajor, b_kmajor;
+    int32_t act;
+    int32_t accumulate;
+} dvae_gemm_desc;
+int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
+
+/* out[r][0:width] (+)= sum_{k in [off[r], off[r+1])} src[idx[k]][0:width]
+ * The gated-sum over predecessors of models.py:661-669 (padding rows of the
+ * reference contribute exactly 0 and are simply absent from the CSR lists). */
+int dvae_gather_sum_f32(float* out, int32_t ld_out, const float* src, int32_t ld_src, const int32_t* off,
+                        const int32_t* idx, int32_t rows, int32_t width, int32_t accumulate, void* stream);
+
+/* dst[idx[k]][0:width] += src[r][0:width] for k in [off[r], off[r+1]); the idx
+ * values must be globally unique (no atomics are used). */
+int dvae_scatter_rows_add_f32(float* dst, int32_t ld_dst, const float* src, int32_t ld_src, const int32_t* off,
+                              const int32_t* idx, int32_t rows, int32_t width, void* stream);
+
+/* torch.nn.GRUCell pointwise part (models.py:670) on a padded layout.
+ * gh [rows][3Hp]: in = h_prev W_hh^T (no bias); out = (r, z, n) activations.
+ * gi_tab [T][3Hp] = W_ih[:, t] + b_ih (+ b_hh for the r and z blocks),
+ * bhn [Hp] = b_hh of the n block, types[rows] selects the gi_tab row,
+ * hprev nullable (zeros).  ghn_out [rows][Hp] keeps W_hn h + b_hn for backward. */
+int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int32_t* types, const float* bhn,
+                           const float* hprev, int32_t ld_hprev, float* hout, int32_t ld_hout, float* ghn_out,
+                           int32_t rows, int32_t Hp, void* stream);
+/* backward of the above: dgh [rows][3Hp] = (d pre_r, d pre_z, d ghn),
+ * dgin [rows][Hp] = d pre_n, dhprev [rows][Hp] = dh * z (direct path). */
+int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const float* gates, const float* ghn,
+                           const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,
+                           int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream);
+
+/* _gated (models.py:628-629) pointwise part: gm [rows][2Hp] in = (Wg h | Wm h),
+ * out = (g = sigmoid(. + gv_g), m = . + gv_m); msg = g * m.  gv [levels][2Hp]
+ * holds the vertex-id column of the gate/mapper weights (+ gate bias); the row
+ * used is (row_base + row) / rows_per_level. */
+int dvae_gated_pointwise_fwd(float* gm, const float* gv, float* msg, int32_t ld_msg, int32_t rows, int32_t Hp,
+                             int32_t row_base, int32_t rows_per_level, void* stream);
+int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, const float* gm, float* dgm, int32_t rows,
+                             int32_t Hp, void* stream);
+
+/* out[seg][0:width] += sum over the seg_rows rows of segment seg of x */
+int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
+                            int32_t seg_rows, int32_t width, void* stream);
+
+/* Edge predictor tail + BCE (models.py:745, :855): per pair p
+ *   s = b2 + sum_j w2[j] relu(EA[a_p][j] + EB[h_p][j] (+ EC[c_p][j]) + b1[j])
+ *   prob = sigmoid(s);  loss_p = -(t log prob + (1-t) log(1-prob)), logs clamped at -100
+ * Writes dl[p] = d loss_p / d s (PyTorch BCE-on-probabilities backward) and adds
+ * sum_p loss_p into *loss_sum.  ec/pair_c nullable (DVAE). */
+int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a,
+                      const int32_t* pair_h, const int32_t* pair_c, const uint8_t* pair_t, const float* b1,
+                      const float* w2, const float* b2, float* dl, float* loss_sum, int32_t n_pairs, int32_t HEp,
+                      void* stream);
+/* Grouped backward pass.  The pairs that share one row of `mine` form a group;
+ * groups are cut into chunks (one wavefront each): chunk q covers
+ * grp_pairs[chunk_off[q] .. chunk_off[q+1]) (grp_pairs NULL: the positions are
+ * the pair ids), chunk_row[q] = the row, with bit 31 set when the row has more
+ * than one chunk (those chunks atomicAdd into the pre-zeroed dmine).
+ *   dmine[row][j] = scale * sum_p dl[p] w2[j] [pre_p[j] > 0],
+ *   pre_p = mine[row] + oth1[oth1_idx[p]] (+ oth2[oth2_idx[p]]) + b1.
+ * dw2_partial (nullable) [n_blocks][HEp] receives per-workgroup partial sums of
+ * scale * dl[p] relu(pre_p[j]). */
+int dvae_pair_bce_bwd_grouped(const float* mine, const int32_t* chunk_off, const int32_t* chunk_row,
+                              const int32_t* grp_pairs, const float* oth1, const int32_t* oth1_idx,
+                              const float* oth2, const int32_t* oth2_idx, const float* b1, const float* w2,
+                              const float* dl, const float* scale, float* dmine, float* dw2_partial,
+                              int32_t n_chunks, int32_t HEp, int32_t n_blocks, void* stream);
+
+/* Vertex-type CE (models.py:823-826): per row of logits [R][ld] with T valid
+ * columns and a CSR list of targets, adds -sum log_softmax[target] into
+ * *loss_sum and writes dlogits[row][0:Tp] = sum_items (softmax - onehot). */
+int dvae_vertex_ce(const float* logits, int32_t ld, const int32_t* ce_off, const int32_t* ce_tgt, float* dlogits,
+                   float* loss_sum, int32_t R, int32_t T, int32_t Tp, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Model description, weights
+ * ------------------------------------------------------------------------- */
+
+/* Constructor arguments of models.DVAE / DVAE_BN (models.py:537, :980). */
+typedef struct dvae_model_desc {
+    int32_t max_n, nvt, hs, nz;
+    int32_t bidir, vid, is_bn;
+    int32_t start_type, end_type;
+} dvae_model_desc;
+
+/* Parameters are passed as an array of DVAE_NUM_PARAMS device pointers in
+ * state_dict order: grue_forward.{weight_ih,weight_hh,bias_ih,
+ * bias_hh}, grue_backward.*, fc1.{weight,bias}, fc2.*, grud.*, fc3.*,
+ * add_vertex.0.*, add_vertex.2.*, add_edge.0.*, add_edge.2.*,
+ * gate_forward.0.{weight,bias}, gate_backward.0.*, mapper_forward.0.weight,
+ * mapper_backward.0.weight, hv_unify.0.{weight,bias}, hg_unify.0.{weight,bias}.
+ * Absent parameters (hv/hg_unify when unidirectional) are NULL. */
+#define DVAE_NUM_PARAMS 36
+
+/* size (floats) of the packed, zero-padded weight buffer / gradient buffer */
+int64_t dvae_packed_floats(const dvae_model_desc* m);
+/* native parameters -> packed buffer (call after every optimizer step) */
+int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream);
+/* packed gradient buffer -> native gradient tensors; want[i] != 0 selects which
+ * of grads[0..DVAE_NUM_PARAMS) are written (fully overwritten). */
+int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const float* packed_g, float* const* grads,
+                      const uint8_t* want, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * DAG batching (host).  Replaces models.py:631-632 (_collate_fn), the per-vertex
+ * gather / zero-pad of models.py:637-668 and util.py:557-573 (batch sharding is
+ * done by the caller choosing which graphs go into a batch).
+ * ------------------------------------------------------------------------- */
+typedef struct dvae_batch_counts {
+    int32_t B, n, T, is_bn;
+    int32_t nB;          /* n * B vertex slots, slot(v, b) = v * B + b          */
+    int32_t E;           /* edges in the batch                                   */
+    int32_t PT, PL;      /* partial-state rows (first T: one per type), list len  */
+    int32_t NA, NB;      /* rows of the two edge-predictor tables                */
+    int32_t NP;          /* vertex pairs = B * n (n-1) / 2                       */
+    int32_t CA, CH, CC;  /* backward chunks grouped by EA row / EB row / graph    */
+    int32_t R, RL, NCE;  /* vertex-type rows, their source-list length, CE items  */
+    int32_t HGF, HGB;    /* graph-state source-list lengths                      */
+    int32_t pad_;
+    int64_t total_ints;  /* size of the exported index blob, in int32            */
+} dvae_batch_counts;
+
+/* HOST pointers: types [B][max_n] (entries past a graph's size ignored),
+ * pred_mask [B][max_n] (bit u of pred_mask[b][v] set iff edge u -> v; vertex ids
+ * are a topological order as in models.py:677), n_vertices [B].  Malformed
+ * input (type out of range, edge u >= v, too many vertices) is rejected. */
+int dvae_batch_create(int32_t B, int32_t max_n, int32_t nvt, int32_t start_type, int32_t is_bn,
+                      const int32_t* types, const uint64_t* pred_mask, const int32_t* n_vertices, void** handle,
+                      dvae_batch_counts* counts);
+/* writes the index blob (counts.total_ints int32) into HOST memory `out` */
+int dvae_batch_export(void* handle, int32_t* out, int64_t out_ints);
+void dvae_batch_destroy(void* handle);
+
+/* ---------------------------------------------------------------------------
+ * The hot path.  `blob` is the exported index blob copied to the device, `pw`
+ * the packed weights, `ws` a workspace of dvae_*_ws_floats() floats that must
+ * stay untouched between a forward and its backward, `pg` a packed gradient
+ * buffer (dvae_packed_floats) that the backward overwrites.
+ * ------------------------------------------------------------------------- */
+int64_t dvae_encode_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c);
+int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c);
+
+/* DVAE.encode, models.py:720-731 (DVAE_BN.encode :1068-1080): mu, logvar [B][nz] */
+int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
+                        float* ws, float* mu, float* logvar, void* stream);
+/* autograd of the above */
+int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
+                         float* ws, const float* dmu, const float* dlogvar, float* pg, void* stream);
+
+/* DVAE.loss, models.py:806-860 (reparameterize :733-740 with the normal draw
+ * `eps` [B][nz] injected): out3 = {res + beta*kld, res, kld}. */
+int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
+                      float* ws, const float* mu, const float* logvar, const float* eps, float eps_scale,
+                      int32_t training, float beta, float* out3, void* stream);
+/* autograd of the above; g3 = upstream gradients of the three outputs */
+int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
+                       float* ws, const float* mu, const float* logvar, const float* eps, float eps_scale,
+                       int32_t training, float beta, const float* g3, float* dmu, float* dlogvar, float* pg,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVAE_HIP_H */

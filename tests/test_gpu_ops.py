@@ -1,0 +1,253 @@
+"""Each HIP kernel on its own, through the C-ABI, against plain PyTorch fp32/fp64
+on the same inputs (tolerances stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from _dvae_pkg import dvae_amd
+
+pytestmark = pytest.mark.gpu
+L = dvae_amd._lib
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None, bias=None, act=0, acc=0):
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
+    d.a_rows = a_rows.data_ptr() if a_rows is not None else None
+    d.b_rows = b_rows.data_ptr() if b_rows is not None else None
+    d.c_rows = c_rows.data_ptr() if c_rows is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), Cm.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.a_kmajor, d.b_kmajor, d.act, d.accumulate = akm, bkm, act, acc
+    L.check(L.load().dvae_gemm_f32(C.byref(d), _s()), "gemm")
+    torch.cuda.synchronize()
+
+
+def _ref(a, b):
+    return (a.double() @ b.double()).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 512), (100, 96, 64), (7, 32, 32), (4000, 2048, 512), (300, 40, 32)])
+def test_gemm_nt_asymmetric(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(A, W, out, M, N, K)
+    ref = _ref(A, W.t())
+    assert (out - ref).abs().max() <= 2e-6 * K ** 0.5 * 16 + 1e-5 * ref.abs().max() * 0
+
+
+def test_gemm_layout_identity_check():
+    # A = I with an asymmetric B catches a transposed C write (guide section 3)
+    K = 64
+    A = torch.eye(K, device="cuda")
+    W = torch.arange(96 * K, device="cuda", dtype=torch.float32).reshape(96, K)
+    out = torch.zeros(K, 96, device="cuda")
+    _gemm(A, W, out, K, 96, K)
+    assert torch.equal(out, W.t().contiguous())
+
+
+def test_gemm_bias_act_accumulate_gather_scatter():
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows_total, M, N, K = 500, 260, 160, 96
+    X = torch.randn(rows_total, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    a_rows = torch.randperm(rows_total, device="cuda", generator=g)[:M].int()
+    c_rows = torch.randperm(400, device="cuda", generator=g)[:M].int()
+    for act in (0, 1, 2):
+        out = torch.ones(400, N, device="cuda")
+        _gemm(X, W, out, M, N, K, a_rows=a_rows, c_rows=c_rows, bias=bias, act=act, acc=1)
+        y = _ref(X[a_rows.long()], W.t()) + bias
+        y = [y, torch.relu(y), torch.tanh(y)][act]
+        ref = torch.ones(400, N, device="cuda")
+        ref[c_rows.long()] += y
+        assert (out - ref).abs().max() < 2e-4
+
+
+def test_gemm_dgrad_kmajor_b():
+    g = torch.Generator(device="cuda").manual_seed(6)
+    M, N, K = 1000, 1536, 512  # dX[M,K] = dY[M,N] W[N,K]
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    out = torch.zeros(M, K, device="cuda")
+    _gemm(dY, W, out, M, K, N, akm=0, bkm=1)
+    ref = _ref(dY, W)
+    assert (out - ref).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("rows,N,K", [(8192, 1536, 512), (333, 64, 32), (5000, 32, 1536), (70, 128, 512)])
+def test_gemm_wgrad_splitk(rows, N, K):
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    dY = torch.randn(rows, N, device="cuda", generator=g)
+    X = torch.randn(rows + 50, K, device="cuda", generator=g)
+    b_rows = torch.randperm(rows + 50, device="cuda", generator=g)[:rows].int()
+    out = torch.zeros(N, K, device="cuda")
+    _gemm(dY, X, out, N, K, rows, akm=1, bkm=1, b_rows=b_rows, acc=1)
+    ref = _ref(dY.t(), X[b_rows.long()])
+    assert (out - ref).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
+
+
+def test_gemm_rejects_bad_shapes():
+    A = torch.zeros(8, 48, device="cuda")
+    out = torch.zeros(8, 8, device="cuda")
+    with pytest.raises(L.DvaeHipError, match="K"):
+        _gemm(A, A, out, 8, 8, 48)
+
+
+def test_gather_sum_and_scatter():
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(300, 64, generator=g).cuda()
+    lens = torch.randint(0, 6, (200,), generator=g)
+    off = torch.zeros(201, dtype=torch.int32)
+    off[1:] = lens.cumsum(0)
+    idx = torch.randint(0, 300, (int(off[-1]),), generator=g).int()
+    out = torch.full((200, 64), float("nan")).cuda()
+    lib = L.load()
+    L.check(lib.dvae_gather_sum_f32(out.data_ptr(), 64, src.data_ptr(), 64, off.cuda().data_ptr(), idx.cuda().data_ptr(),
+                                    200, 64, 0, _s()))
+    ref = torch.zeros(200, 64)
+    for r in range(200):
+        for k in range(off[r], off[r + 1]):
+            ref[r] += src[idx[k]].cpu()
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    # scatter with unique indices
+    perm = torch.randperm(300, generator=g)[: int(off[-1])].int() if off[-1] <= 300 else None
+    if perm is not None:
+        dst = torch.ones(300, 64).cuda()
+        L.check(lib.dvae_scatter_rows_add_f32(dst.data_ptr(), 64, out.data_ptr(), 64, off.cuda().data_ptr(),
+                                              perm.cuda().data_ptr(), 200, 64, _s()))
+        ref2 = torch.ones(300, 64)
+        for r in range(200):
+            for k in range(off[r], off[r + 1]):
+                ref2[perm[k]] += out[r].cpu()
+        assert (dst.cpu() - ref2).abs().max() < 1e-5
+
+
+def test_gru_pointwise_matches_torch_grucell():
+    torch.manual_seed(3)
+    H, Hp, T, rows = 20, 32, 5, 37
+    cell = torch.nn.GRUCell(T, H).cuda()
+    types = torch.randint(0, T, (rows,), device="cuda")
+    hprev = torch.randn(rows, H, device="cuda", requires_grad=True)
+    x = torch.nn.functional.one_hot(types, T).float()
+    ref = cell(x, hprev)
+    dh = torch.randn_like(ref)
+    ref.backward(dh)
+    # padded operands
+    gh = torch.zeros(rows, 3 * Hp, device="cuda")
+    gi = torch.zeros(T, 3 * Hp, device="cuda")
+    bhn = torch.zeros(Hp, device="cuda")
+    hp = torch.zeros(rows, Hp, device="cuda")
+    hp[:, :H] = hprev.detach()
+    ghraw = hprev.detach() @ cell.weight_hh.t()
+    for q in range(3):
+        gh[:, q * Hp:q * Hp + H] = ghraw[:, q * H:(q + 1) * H]
+        gi[:, q * Hp:q * Hp + H] = (cell.weight_ih[q * H:(q + 1) * H, :].t() + cell.bias_ih[q * H:(q + 1) * H]
+                                    + (cell.bias_hh[q * H:(q + 1) * H] if q < 2 else 0)).detach()
+    bhn[:H] = cell.bias_hh[2 * H:].detach()
+    hout = torch.zeros(rows, Hp, device="cuda")
+    ghn = torch.zeros(rows, Hp, device="cuda")
+    lib = L.load()
+    L.check(lib.dvae_gru_pointwise_fwd(gh.data_ptr(), gi.data_ptr(), types.int().data_ptr(), bhn.data_ptr(), hp.data_ptr(),
+                                       Hp, hout.data_ptr(), Hp, ghn.data_ptr(), rows, Hp, _s()))
+    assert (hout[:, :H] - ref.detach()).abs().max() < 1e-6
+    assert hout[:, H:].abs().max() == 0
+    dhp = torch.zeros(rows, Hp, device="cuda")
+    dhp[:, :H] = dh
+    dgh = torch.zeros(rows, 3 * Hp, device="cuda")
+    dgin = torch.zeros(rows, Hp, device="cuda")
+    dprev = torch.zeros(rows, Hp, device="cuda")
+    L.check(lib.dvae_gru_pointwise_bwd(dhp.data_ptr(), Hp, gh.data_ptr(), ghn.data_ptr(), hp.data_ptr(), Hp,
+                                       dgh.data_ptr(), dgin.data_ptr(), dprev.data_ptr(), Hp, rows, Hp, _s()))
+    # d hprev = direct + dgh @ Whh
+    dgh_n = torch.cat([dgh[:, q * Hp:q * Hp + H] for q in range(3)], 1)
+    dh_total = dprev[:, :H] + dgh_n @ cell.weight_hh.detach()
+    assert (dh_total - hprev.grad).abs().max() < 2e-6
+    dWhh = dgh_n.t() @ hprev.detach()
+    assert (dWhh - cell.weight_hh.grad).abs().max() < 2e-5
+    dbhh = dgh_n.sum(0)
+    assert (dbhh - cell.bias_hh.grad).abs().max() < 2e-5
+    dgi_n = torch.cat([dgh[:, :Hp][:, :H], dgh[:, Hp:2 * Hp][:, :H], dgin[:, :H]], 1)
+    assert (dgi_n.sum(0) - cell.bias_ih.grad).abs().max() < 2e-5
+
+
+def test_pair_kernels_match_torch():
+    torch.manual_seed(4)
+    HEp, NA, NB, NP = 96, 11, 13, 150
+    ea = torch.randn(NA + 1, HEp, device="cuda", requires_grad=True)
+    eb = torch.randn(NB + 1, HEp, device="cuda", requires_grad=True)
+    b1 = torch.randn(HEp, device="cuda", requires_grad=True)
+    w2 = torch.randn(HEp, device="cuda", requires_grad=True)
+    b2 = torch.randn(1, device="cuda", requires_grad=True)
+    pa = torch.randint(0, NA + 1, (NP,), device="cuda")
+    ph = torch.randint(0, NB + 1, (NP,), device="cuda")
+    tgt = torch.randint(0, 2, (NP,), device="cuda")
+    s = (torch.relu(ea[pa] + eb[ph] + b1) * w2).sum(1) + b2
+    ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(s), tgt.float(), reduction="sum")
+    ref.backward()
+    lib = L.load()
+    dl = torch.zeros(NP, device="cuda")
+    lsum = torch.zeros(1, device="cuda")
+    L.check(lib.dvae_pair_bce_fwd(ea.data_ptr(), eb.data_ptr(), None, pa.int().data_ptr(), ph.int().data_ptr(), None,
+                                  tgt.to(torch.uint8).data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                  dl.data_ptr(), lsum.data_ptr(), NP, HEp, _s()))
+    assert abs(lsum.item() - ref.item()) < 1e-4 * ref.item()
+    assert abs(dl.sum().item() - b2.grad.item()) < 1e-4
+    # grouped backward by the EA row, chunks of 4 pairs
+    def chunks(key, nrows, ch):
+        order = torch.argsort(key.cpu(), stable=True)
+        cnt = torch.bincount(key.cpu(), minlength=nrows)
+        off, row, start = [], [], 0
+        for r in range(nrows):
+            multi = cnt[r] > ch
+            for s0 in range(0, int(cnt[r]), ch):
+                off.append(start + s0)
+                row.append(r | (0x80000000 if multi else 0))
+            start += int(cnt[r])
+        off.append(NP)
+        row = np.array(row, np.uint32).view(np.int32)
+        return (torch.tensor(off, dtype=torch.int32).cuda(), torch.from_numpy(row).cuda(), order.int().cuda())
+    for mine, key, nrows, oth, oidx, gref in ((ea, pa, NA + 1, eb, ph, ea.grad), (eb, ph, NB + 1, ea, pa, eb.grad)):
+        off, row, pairs = chunks(key, nrows, 4)
+        dm = torch.zeros_like(mine)
+        nblk = 8
+        dw2p = torch.zeros(nblk, HEp, device="cuda")
+        L.check(lib.dvae_pair_bce_bwd_grouped(mine.data_ptr(), off.data_ptr(), row.data_ptr(), pairs.data_ptr(),
+                                              oth.data_ptr(), oidx.int().data_ptr(), None, None, b1.data_ptr(),
+                                              w2.data_ptr(), dl.data_ptr(), None, dm.data_ptr(), dw2p.data_ptr(),
+                                              row.numel(), HEp, nblk, _s()))
+        assert (dm - gref).abs().max() < 1e-4
+        assert (dw2p.sum(0) - w2.grad).abs().max() < 1e-3
+    assert (ea.grad.sum(0) - b1.grad).abs().max() < 1e-3  # db1 = column sum of dEA
+
+
+def test_vertex_ce_matches_torch():
+    torch.manual_seed(5)
+    R, T, Tp = 70, 8, 32
+    logits = torch.randn(R, Tp, device="cuda")
+    lg = logits[:, :T].clone().requires_grad_(True)
+    cnt = torch.randint(1, 4, (R,))
+    off = torch.zeros(R + 1, dtype=torch.int32)
+    off[1:] = cnt.cumsum(0)
+    tg = torch.randint(0, T, (int(off[-1]),))
+    lsm = torch.log_softmax(lg, 1)
+    ref = 0
+    for r in range(R):
+        for k in range(off[r], off[r + 1]):
+            ref = ref - lsm[r, tg[k]]
+    ref.backward()
+    dlog = torch.zeros(R, Tp, device="cuda")
+    lsum = torch.zeros(1, device="cuda")
+    L.check(L.load().dvae_vertex_ce(logits.data_ptr(), Tp, off.cuda().data_ptr(), tg.int().cuda().data_ptr(),
+                                    dlog.data_ptr(), lsum.data_ptr(), R, T, Tp, _s()))
+    assert abs(lsum.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert (dlog[:, :T] - lg.grad).abs().max() < 1e-5 and dlog[:, T:].abs().max() == 0

@@ -1,0 +1,169 @@
+"""End-to-end parity of the HIP train step (through the drop-in modules and the
+C-ABI) against (a) golden vectors produced by the reference, (b) the oracle on
+seeded inputs, (c) size-independent properties at BASELINE batch sizes.
+
+Tolerance: fp32, relative 1e-4 on loss / mu / logvar / gradients (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _dvae_pkg import dvae_amd
+from common import golden_files, load_case, cfg_of, make_model, state_dict_of, rel_err
+import dvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+TINY = golden_files("*tiny*")
+BIG = golden_files("*cfg*")
+TOL = 1e-4
+
+
+def _run(model, ga, eps):
+    model.train()
+    model.zero_grad()
+    batch = model._collate_fn(ga)
+    mu, logvar = model.encode(batch)
+    loss, res, kld = model.loss(mu, logvar, batch, eps=eps)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, res, kld, mu, logvar
+
+
+@pytest.mark.parametrize("path", TINY, ids=[os.path.basename(p)[:-4] for p in TINY])
+def test_tiny_matches_reference_golden(path):
+    d, cls, ctor = load_case(path)
+    model = make_model(cls, ctor)
+    model.load_state_dict(state_dict_of(d))
+    model.cuda()
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    loss, res, kld, mu, logvar = _run(model, ga, torch.from_numpy(d["eps"]))
+    ref = d["loss3"]
+    assert abs(loss.item() - ref[0]) <= TOL * abs(ref[0])
+    assert abs(res.item() - ref[1]) <= TOL * abs(ref[1])
+    assert abs(kld.item() - ref[2]) <= TOL * abs(ref[2]) + 1e-6
+    assert rel_err(mu, torch.from_numpy(d["mu"])) < TOL
+    assert rel_err(logvar, torch.from_numpy(d["logvar"])) < TOL
+    none = sorted(k for k, p in model.named_parameters() if p.grad is None)
+    assert none == sorted(x for x in d["none_grads"].tolist() if x)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad, torch.from_numpy(d["grad::" + k])) < TOL, k
+
+
+@pytest.mark.parametrize("path", BIG, ids=[os.path.basename(p)[:-4] for p in BIG])
+def test_hs501_matches_reference_golden(path):
+    d, cls, ctor = load_case(path)
+    model = make_model(cls, ctor, int(d["seed"])).cuda()
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    loss, res, kld, mu, logvar = _run(model, ga, torch.from_numpy(d["eps"]))
+    ref = d["loss3"]
+    assert abs(loss.item() - ref[0]) <= TOL * abs(ref[0])
+    assert abs(kld.item() - ref[2]) <= TOL * abs(ref[2])
+    assert rel_err(mu, torch.from_numpy(d["mu"])) < TOL
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert k in d["none_grads"].tolist()
+            continue
+        gn = d["gnorm::" + k]
+        assert abs(p.grad.double().norm().item() - gn[0]) <= TOL * gn[0] + 1e-9, k
+        sl = torch.from_numpy(d["gslice::" + k])
+        got = p.grad.reshape(-1)[:sl.numel()].cpu()
+        assert (got - sl).abs().max() <= TOL * max(gn[0] / p.numel() ** 0.5, sl.abs().max().item()) * 10 + 1e-7, k
+
+
+def _random_batch(rng, B, n, T, p_edge, var=False):
+    types = np.zeros((B, n), np.int64)
+    adj = np.zeros((B, n, n), np.uint8)
+    n_g = np.full((B,), n, np.int64)
+    for b in range(B):
+        k = int(rng.integers(3, n + 1)) if var else n
+        n_g[b] = k
+        types[b, 0] = 0
+        types[b, 1:k - 1] = rng.integers(2, T, size=k - 2)
+        types[b, k - 1] = 1
+        for v in range(1, k):
+            adj[b, v - 1, v] = 1
+            for u in range(v - 1):
+                adj[b, u, v] = rng.random() < p_edge
+    return types, adj, n_g
+
+
+@pytest.mark.parametrize("cls,bidir,var", [("DVAE", True, False), ("DVAE", False, True), ("DVAE_BN", True, True)])
+def test_random_graphs_match_oracle(cls, bidir, var):
+    """Seeded random DAG batches (incl. ragged sizes) at hs=72 vs the oracle's autograd."""
+    rng = np.random.default_rng(11)
+    n, T, hs, nz, B = 9, 7, 72, 10, 40
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=int(bidir))
+    model = make_model(cls, ctor, 3)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.35, var)
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    cfg = cfg_of(cls, ctor)
+    Lr, Rr, Kr, mur, lvr, gr = O.train_step_grads(cfg, sd, torch.from_numpy(types), torch.from_numpy(adj),
+                                                   torch.from_numpy(n_g), eps)
+    model.cuda()
+    loss, res, kld, mu, logvar = _run(model, dvae_amd.GraphArrays.from_dense(types, adj, n_g), eps)
+    assert abs(loss.item() - Lr.item()) <= TOL * abs(Lr.item())
+    assert rel_err(mu, mur) < TOL and rel_err(logvar, lvr) < TOL
+    for k, p in model.named_parameters():
+        if gr[k] is None:
+            assert p.grad is None, k
+        else:
+            assert rel_err(p.grad, gr[k]) < TOL, k
+
+
+def test_single_graph_and_eval_mode():
+    d, cls, ctor = load_case(golden_files("dvae_tiny_bi_full")[0])
+    model = make_model(cls, ctor)
+    model.load_state_dict(state_dict_of(d))
+    model.cuda().eval()
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    with torch.no_grad():
+        mu_all, _ = model.encode(ga)
+        mu_1, lv_1 = model.encode(ga[2:3])
+        assert rel_err(mu_1, mu_all[2:3]) < 1e-5
+        l_eval, _, _ = model.loss(mu_all, torch.zeros_like(mu_all), ga)
+    cfg = cfg_of(cls, ctor)
+    sd = state_dict_of(d)
+    types, adj, n_g = (torch.from_numpy(d[k]) for k in ("types", "adj", "n_g"))
+    mu_o, _ = O.encode(cfg, sd, types, adj, n_g)
+    l_o, _, _ = O.loss(cfg, sd, mu_o, torch.zeros_like(mu_o), types, adj, n_g, None, training=False)
+    assert abs(l_eval.item() - l_o.item()) <= TOL * abs(l_o.item())
+
+
+def test_full_batch_properties_cfg2():
+    """BASELINE config 2 size (B=1024, bidirectional, hs=501): properties that do
+    not need the oracle at full size -- the loss is a SUM over independent graphs
+    (models.py:825,855,859), so two half-batches add up to the full batch, in the
+    loss and in every gradient; and a 32-graph slice still matches the oracle."""
+    rng = np.random.default_rng(2)
+    n, T, B = 8, 8, 1024
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=501, nz=56, bidirectional=1)
+    model = make_model("DVAE", ctor, 1).cuda()
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.3)
+    eps = torch.from_numpy(rng.standard_normal((B, 56)).astype(np.float32))
+    ga = dvae_amd.GraphArrays.from_dense(types, adj, n_g)
+    loss, res, kld, mu, logvar = _run(model, ga, eps)
+    g_full = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    tot, g_sum = 0.0, None
+    for lo, hi in ((0, 512), (512, 1024)):
+        l2, _, _, mu2, _ = _run(model, ga[lo:hi], eps[lo:hi])
+        tot += l2.item()
+        assert rel_err(mu2, mu[lo:hi]) < 1e-5
+        cur = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        g_sum = cur if g_sum is None else {k: g_sum[k] + cur[k] for k in cur}
+    assert abs(tot - loss.item()) <= 2e-5 * abs(loss.item())
+    for k in g_full:
+        assert rel_err(g_sum[k], g_full[k]) < TOL, k
+    # oracle on a slice
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sl = slice(100, 116)
+    Lr, _, _, mur, _, gr = O.train_step_grads(cfg_of("DVAE", ctor), sd, torch.from_numpy(types[sl]),
+                                              torch.from_numpy(adj[sl]), torch.from_numpy(n_g[sl]), eps[sl])
+    l3, _, _, mu3, _ = _run(model, ga[sl], eps[sl])
+    assert abs(l3.item() - Lr.item()) <= TOL * abs(Lr.item())
+    assert rel_err(mu3, mur) < TOL
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad, gr[k]) < TOL, k

@@ -1,0 +1,120 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports every
+declared symbol, the DAG packer's tables reproduce the oracle's loss when
+interpreted on the CPU, malformed graphs are rejected, module layout matches the
+reference's state_dict."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _dvae_pkg import dvae_amd
+from common import golden_files, load_case, cfg_of, make_model, state_dict_of
+import blob_interp as BI
+import dvae_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = golden_files("*tiny*")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = dvae_amd._lib.load()
+    header = open(os.path.join(ROOT, "include", "dvae_hip.h")).read()
+    declared = set(re.findall(r"\b(dvae_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(dvae_amd._lib.SIGNATURES.keys())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dvae_version() >= 100
+
+
+def test_compute_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d, cls, ctor = load_case(TINY[0])
+    model = make_model(cls, ctor)
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    with pytest.raises(dvae_amd._lib.DvaeHipError):
+        model.encode(ga)
+
+
+@pytest.mark.parametrize("path", TINY, ids=[os.path.basename(p)[:-4] for p in TINY])
+def test_packer_tables_reproduce_reference_loss(path):
+    d, cls, ctor = load_case(path)
+    cfg = cfg_of(cls, ctor)
+    sd = state_dict_of(d, torch.float64)
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    b = dvae_amd.DAGBatch(ga, ctor["nvt"], 0, cls == "DVAE_BN", "cpu")
+    mu, lv, (L, R, K) = BI.forward(cfg, sd, b, torch.from_numpy(d["eps"]).double())
+    assert abs(L.item() - d["loss3"][0]) < 1e-6 * d["loss3"][0]
+    assert (mu.float() - torch.from_numpy(d["mu"])).abs().max() < 1e-6
+
+
+def test_packer_counts_and_dedup():
+    d, cls, ctor = load_case(golden_files("dvae_cfg1_uni")[0])
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    b = dvae_amd.DAGBatch(ga, 8, 0, False, "cpu")
+    c = b.counts
+    B, n = 32, 8
+    E = int(d["adj"].sum())
+    assert (c.B, c.n, c.nB, c.E, c.NP) == (B, n, B * n, E, B * n * (n - 1) // 2)
+    # distinct partial rows: one per type + (indeg - 1) per vertex with indeg >= 2
+    indeg = d["adj"].astype(np.int64).sum(1)
+    assert c.PT == 8 + int(np.maximum(indeg - 1, 0).sum())
+    assert c.R == B * (n - 1) and c.NCE == B * (n - 1)
+    t = BI.unpack_blob(b)
+    # every pair points at valid table rows; targets equal the adjacency
+    assert t["pair_a"].max() <= c.NA and t["pair_h"].max() <= c.NB
+    assert int(t["pair_t"].sum()) == E
+    # chunk tables cover every pair exactly once
+    for key in ("ca", "ch"):
+        assert sorted(t[key + "_pairs"].tolist()) == list(range(c.NP))
+
+
+def test_graph_objects_and_arrays_agree():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "igraph_standin"))
+    import graph_rows
+    d, cls, ctor = load_case(golden_files("dvae_tiny_uni_var")[0])
+    graphs = [graph_rows.decode_ENAS_to_igraph(r)[0] for r in d["rows"].tolist()]
+    ga = dvae_amd.graphs_to_arrays(graphs, 8)
+    types, adj, n_g = ga.to_dense()
+    assert (n_g == d["n_g"]).all() and (adj == d["adj"]).all()
+    for b, k in enumerate(n_g):
+        assert (types[b, :k] == d["types"][b, :k]).all()
+
+
+def test_malformed_graphs_are_rejected():
+    types = np.zeros((1, 4), np.int32)
+    types[0] = [0, 2, 3, 1]
+    ok = np.array([[0, 1, 3, 4]], np.uint64)
+    n_g = np.array([4], np.int32)
+    dvae_amd.DAGBatch(dvae_amd.GraphArrays(types, ok, n_g, 4), 5, 0, False, "cpu")
+    with pytest.raises(dvae_amd._lib.DvaeHipError, match="topological"):
+        bad = ok.copy(); bad[0, 1] = 0b100  # edge 2 -> 1
+        dvae_amd.DAGBatch(dvae_amd.GraphArrays(types, bad, n_g, 4), 5, 0, False, "cpu")
+    with pytest.raises(dvae_amd._lib.DvaeHipError, match="type"):
+        t2 = types.copy(); t2[0, 2] = 7
+        dvae_amd.DAGBatch(dvae_amd.GraphArrays(t2, ok, n_g, 4), 5, 0, False, "cpu")
+    with pytest.raises(dvae_amd._lib.DvaeHipError, match="vertices"):
+        dvae_amd.DAGBatch(dvae_amd.GraphArrays(types, ok, np.array([5], np.int32), 4), 5, 0, False, "cpu")
+    with pytest.raises(ValueError):
+        dvae_amd.DAGBatch(dvae_amd.GraphArrays(types[:0], ok[:0], n_g[:0], 4), 5, 0, False, "cpu")
+
+
+def test_state_dict_layout_matches_reference():
+    for path in golden_files("*cfg*") + golden_files("*tiny_bi_full"):
+        d, cls, ctor = load_case(path)
+        model = make_model(cls, ctor, int(d["seed"]))
+        assert list(model.state_dict().keys()) == d["param_names"].tolist()
+        for k, w in model.state_dict().items():
+            s = d["psum::" + k]
+            assert abs(w.double().sum().item() - s[0]) < 1e-9, k
+
+
+def test_shard_bounds_is_ceil_split():
+    # util.py:566-572: contiguous chunks of ceil(B / ndev)
+    assert [dvae_amd.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [dvae_amd.shard_bounds(8, 2, r) for r in range(2)] == [(0, 4), (4, 8)]
+    assert dvae_amd.shard_bounds(2, 4, 3) == (2, 2)
