@@ -43,3 +43,36 @@ def state_dict_of(d, dtype=torch.float32):
 def rel_err(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def oracle_truth(cls, ctor, sd, types, adj, n_g, eps):
+    """fp64 oracle (the truth) and fp32 oracle (what the reference computes: it is
+    pinned to the reference's golden vectors by tests/test_oracle_golden.py)."""
+    cfg = cfg_of(cls, ctor)
+    t = [torch.as_tensor(x) for x in (types, adj, n_g)]
+    r32 = O.train_step_grads(cfg, {k: v.float() for k, v in sd.items()}, t[0], t[1], t[2], eps.float())
+    r64 = O.train_step_grads(cfg, {k: v.double() for k, v in sd.items()}, t[0], t[1], t[2], eps.double())
+    return r32, r64
+
+
+def assert_grads_match(model, r32, r64, tol=1e-4, slack=1.5):
+    """Gradient parity.  The decoder's ReLU layers make the gradient discontinuous:
+    a pre-activation within fp32 rounding of 0 flips its mask, and ONE flip moves
+    a gradient tensor by ~1e-3 relative.  The reference's own fp32 run therefore
+    sits up to ~2e-3 away from its exact (fp64) value at hs=501 (measured:
+    DESIGN.md 'Parity').  The bar per parameter is
+        rel_err(HIP, fp64 oracle) <= tol + slack * rel_err(fp32 oracle, fp64 oracle)
+    i.e. the HIP gradient is as close to the exact gradient as the reference's is;
+    where no flip occurs this is the plain `tol` = 1e-4 of north_star."""
+    worst = 0.0
+    for k, p in model.named_parameters():
+        g64 = r64[5][k]
+        if g64 is None:
+            assert p.grad is None, "%s must have no gradient" % k
+            continue
+        assert p.grad is not None, k
+        e_ref = rel_err(r32[5][k], g64)
+        e_hip = rel_err(p.grad, g64)
+        worst = max(worst, e_hip)
+        assert e_hip <= tol + slack * e_ref, "%s: hip-vs-exact %.3e, reference-vs-exact %.3e" % (k, e_hip, e_ref)
+    return worst

@@ -112,7 +112,8 @@ def test_gather_sum_and_scatter():
     idx = torch.randint(0, 300, (int(off[-1]),), generator=g).int()
     out = torch.full((200, 64), float("nan")).cuda()
     lib = L.load()
-    L.check(lib.dvae_gather_sum_f32(out.data_ptr(), 64, src.data_ptr(), 64, off.cuda().data_ptr(), idx.cuda().data_ptr(),
+    off_d, idx_d = off.cuda(), idx.cuda()  # keep the device copies alive across the call
+    L.check(lib.dvae_gather_sum_f32(out.data_ptr(), 64, src.data_ptr(), 64, off_d.data_ptr(), idx_d.data_ptr(),
                                     200, 64, 0, _s()))
     ref = torch.zeros(200, 64)
     for r in range(200):
@@ -123,8 +124,9 @@ def test_gather_sum_and_scatter():
     perm = torch.randperm(300, generator=g)[: int(off[-1])].int() if off[-1] <= 300 else None
     if perm is not None:
         dst = torch.ones(300, 64).cuda()
-        L.check(lib.dvae_scatter_rows_add_f32(dst.data_ptr(), 64, out.data_ptr(), 64, off.cuda().data_ptr(),
-                                              perm.cuda().data_ptr(), 200, 64, _s()))
+        perm_d = perm.cuda()
+        L.check(lib.dvae_scatter_rows_add_f32(dst.data_ptr(), 64, out.data_ptr(), 64, off_d.data_ptr(),
+                                              perm_d.data_ptr(), 200, 64, _s()))
         ref2 = torch.ones(300, 64)
         for r in range(200):
             for k in range(off[r], off[r + 1]):
@@ -157,7 +159,8 @@ def test_gru_pointwise_matches_torch_grucell():
     hout = torch.zeros(rows, Hp, device="cuda")
     ghn = torch.zeros(rows, Hp, device="cuda")
     lib = L.load()
-    L.check(lib.dvae_gru_pointwise_fwd(gh.data_ptr(), gi.data_ptr(), types.int().data_ptr(), bhn.data_ptr(), hp.data_ptr(),
+    types_i = types.int()
+    L.check(lib.dvae_gru_pointwise_fwd(gh.data_ptr(), gi.data_ptr(), types_i.data_ptr(), bhn.data_ptr(), hp.data_ptr(),
                                        Hp, hout.data_ptr(), Hp, ghn.data_ptr(), rows, Hp, _s()))
     assert (hout[:, :H] - ref.detach()).abs().max() < 1e-6
     assert hout[:, H:].abs().max() == 0
@@ -197,8 +200,9 @@ def test_pair_kernels_match_torch():
     lib = L.load()
     dl = torch.zeros(NP, device="cuda")
     lsum = torch.zeros(1, device="cuda")
-    L.check(lib.dvae_pair_bce_fwd(ea.data_ptr(), eb.data_ptr(), None, pa.int().data_ptr(), ph.int().data_ptr(), None,
-                                  tgt.to(torch.uint8).data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+    pa_i, ph_i, tgt_u = pa.int(), ph.int(), tgt.to(torch.uint8)
+    L.check(lib.dvae_pair_bce_fwd(ea.data_ptr(), eb.data_ptr(), None, pa_i.data_ptr(), ph_i.data_ptr(), None,
+                                  tgt_u.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                   dl.data_ptr(), lsum.data_ptr(), NP, HEp, _s()))
     assert abs(lsum.item() - ref.item()) < 1e-4 * ref.item()
     assert abs(dl.sum().item() - b2.grad.item()) < 1e-4
@@ -216,13 +220,13 @@ def test_pair_kernels_match_torch():
         off.append(NP)
         row = np.array(row, np.uint32).view(np.int32)
         return (torch.tensor(off, dtype=torch.int32).cuda(), torch.from_numpy(row).cuda(), order.int().cuda())
-    for mine, key, nrows, oth, oidx, gref in ((ea, pa, NA + 1, eb, ph, ea.grad), (eb, ph, NB + 1, ea, pa, eb.grad)):
+    for mine, key, nrows, oth, oidx, gref in ((ea, pa, NA + 1, eb, ph_i, ea.grad), (eb, ph, NB + 1, ea, pa_i, eb.grad)):
         off, row, pairs = chunks(key, nrows, 4)
         dm = torch.zeros_like(mine)
         nblk = 8
         dw2p = torch.zeros(nblk, HEp, device="cuda")
         L.check(lib.dvae_pair_bce_bwd_grouped(mine.data_ptr(), off.data_ptr(), row.data_ptr(), pairs.data_ptr(),
-                                              oth.data_ptr(), oidx.int().data_ptr(), None, None, b1.data_ptr(),
+                                              oth.data_ptr(), oidx.data_ptr(), None, None, b1.data_ptr(),
                                               w2.data_ptr(), dl.data_ptr(), None, dm.data_ptr(), dw2p.data_ptr(),
                                               row.numel(), HEp, nblk, _s()))
         assert (dm - gref).abs().max() < 1e-4
@@ -247,7 +251,8 @@ def test_vertex_ce_matches_torch():
     ref.backward()
     dlog = torch.zeros(R, Tp, device="cuda")
     lsum = torch.zeros(1, device="cuda")
-    L.check(L.load().dvae_vertex_ce(logits.data_ptr(), Tp, off.cuda().data_ptr(), tg.int().cuda().data_ptr(),
+    off_d, tg_d = off.cuda(), tg.int().cuda()
+    L.check(L.load().dvae_vertex_ce(logits.data_ptr(), Tp, off_d.data_ptr(), tg_d.data_ptr(),
                                     dlog.data_ptr(), lsum.data_ptr(), R, T, Tp, _s()))
     assert abs(lsum.item() - ref.item()) < 1e-4 * abs(ref.item())
     assert (dlog[:, :T] - lg.grad).abs().max() < 1e-5 and dlog[:, T:].abs().max() == 0
