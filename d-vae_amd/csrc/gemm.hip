@@ -31,6 +31,8 @@
 namespace dvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer offset past num_records: the load returns 0
 
 struct GemmParams {
     const float* A; const float* B; float* C;
@@ -47,50 +49,125 @@ struct GemmParams {
 constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
 
-template <int ROWS, bool KMAJOR>
+// Register-staged tile loader.  Everything that does not depend on the K step
+// (row gather, row clamping, column guards) is resolved ONCE in init(); the K loop
+// then issues UNITS independent 16-byte loads back to back with no branch between
+// them.  The staging registers and row pointers are NAMED scalars (r0..r3, p0..p3),
+// not arrays: as arrays hipcc left them in scratch memory across the loop back-edge
+// (scratch_store / scratch_load of every staged tile, ScratchSize 144 B/lane).
+template <int ROWS, bool KMAJOR, bool KGATHER>
 struct TileLoader {
-    // number of float4 units per thread
-    static constexpr int UNITS = ROWS * BK / 4 / 256;
+    static constexpr int UNITS = ROWS * BK / 4 / 256;  // float4 units per thread: 1, 2 or 4
     static constexpr int LDS_ELEMS = KMAJOR ? BK * ROWS : ROWS * KC_LD;
-    float4 regs[UNITS];
+    static_assert(UNITS == 1 || UNITS == 2 || UNITS == 4, "tile rows must be 32, 64 or 128");
+    float4 r0, r1, r2, r3;
+    const float *p0, *p1, *p2, *p3;  // K-contig: row base (+ c4*4); K-major: base + column
+    bool c0, c1, c2, c3;             // K-major: column inside the matrix
+    const int* rows_;
+    int ld_;
 
-    // K-contig: unit u -> row u/8, c4 u%8 ; global addr = base + ridx(row)*ld + k0 + c4*4
-    // K-major : unit u -> k u/(ROWS/4), m4 u%(ROWS/4); addr = base + ridx(k0+k)*ld + r0 + m4*4
-    __device__ __forceinline__ void load(const float* __restrict__ base, const int* __restrict__ rows, int ld,
-                                         int r0, int rdim, int k0, int kend, int tid) {
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            int u = tid + 256 * i;
-            if (!KMAJOR) {
-                int row = u >> 3, c4 = u & 7;
-                int r = r0 + row;
-                r = r < rdim ? r : rdim - 1;
-                long ridx = rows ? (long)rows[r] : (long)r;
-                regs[i] = *reinterpret_cast<const float4*>(base + ridx * ld + k0 + c4 * 4);
-            } else {
-                int k = u / (ROWS / 4), m4 = u % (ROWS / 4);
-                int kk = k0 + k;
-                int r = r0 + m4 * 4;
-                if (kk < kend && r < rdim) {
-                    long ridx = rows ? (long)rows[kk] : (long)kk;
-                    regs[i] = *reinterpret_cast<const float4*>(base + ridx * ld + r);
-                } else {
-                    regs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+    // K-contig: unit u -> row u/8, c4 u%8.   K-major: unit u -> k u/(ROWS/4), m4 u%(ROWS/4)
+    __device__ __forceinline__ void init1(const float*& ptr, bool& colok, unsigned& col, int i,
+                                          const float* __restrict__ base, const int* __restrict__ rows, int ld,
+                                          int r0_, int rdim, int tid) {
+        int u = tid + 256 * i;
+        if (!KMAJOR) {
+            int row = u >> 3, c4 = u & 7;
+            int r = r0_ + row;
+            r = r < rdim ? r : rdim - 1;  // clamped rows are computed but never stored
+            long ridx = rows ? (long)rows[r] : (long)r;
+            ptr = base + ridx * ld + c4 * 4;
+            colok = true;
+            col = 0;
+        } else {
+            int m4 = u % (ROWS / 4);
+            int r = r0_ + m4 * 4;
+            colok = r < rdim;
+            col = (unsigned)r;
+            ptr = base;
+        }
+    }
+    __device__ __forceinline__ void init(const float* __restrict__ base, const int* __restrict__ rows, int ld, int r0_,
+                                         int rdim, int tid) {
+        rows_ = rows;
+        ld_ = ld;
+        if (KMAJOR) rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, OOB, 0x00020000);
+        init1(p0, c0, col0_, 0, base, rows, ld, r0_, rdim, tid);
+        if (UNITS > 1) init1(p1, c1, col1_, 1, base, rows, ld, r0_, rdim, tid);
+        if (UNITS > 2) {
+            init1(p2, c2, col2_, 2, base, rows, ld, r0_, rdim, tid);
+            init1(p3, c3, col3_, 3, base, rows, ld, r0_, rdim, tid);
+        }
+    }
+    // K-major operands are read with buffer loads through a raw descriptor whose range
+    // check supplies the zeros: an element outside the matrix (k >= kend in the last tile
+    // of a split, column >= rdim at the tile edge) gets the byte offset OOB and the hardware
+    // returns 0 -- no branch, and no instruction depends on the loaded data before the LDS
+    // store (a select on the data is hoisted to the top of the next step by hipcc and exposes
+    // the load latency; a select between pointers of two address spaces becomes branches).
+    // Consequence: a K-major operand must lie within 4 GiB of its base pointer.
+    // With KGATHER the row indices are themselves loaded one tile ahead of the data
+    // (next_idx), so the data loads never wait on an index load.
+    __amdgpu_buffer_rsrc_t rsrc_;
+    unsigned col0_, col1_, col2_, col3_;  // column (elements) of each unit, or OOB
+    int n0_, n1_, n2_, n3_;               // gathered row indices of the NEXT tile to load
+    __device__ __forceinline__ int kclamp(int i, int k0, int kend, int tid) {
+        int kk = k0 + (tid + 256 * i) / (ROWS / 4);
+        return kk < kend ? kk : kend - 1;
+    }
+    __device__ __forceinline__ float4 kload(int i, int k0, int kend, int tid, bool colok, unsigned col, int nidx) {
+        int kk = k0 + (tid + 256 * i) / (ROWS / 4);
+        bool ok = kk < kend && colok;
+        unsigned ridx = KGATHER ? (unsigned)nidx : (unsigned)kk;
+        unsigned off = ok ? (ridx * (unsigned)ld_ + col) * 4u : OOB;
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    // call once before the first load(k0) and after every load: fetches indices for tile knext
+    __device__ __forceinline__ void next_idx(int knext, int kend, int tid) {
+        if (KMAJOR && KGATHER) {
+            n0_ = rows_[kclamp(0, knext, kend, tid)];
+            if (UNITS > 1) n1_ = rows_[kclamp(1, knext, kend, tid)];
+            if (UNITS > 2) {
+                n2_ = rows_[kclamp(2, knext, kend, tid)];
+                n3_ = rows_[kclamp(3, knext, kend, tid)];
             }
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) {
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            int u = tid + 256 * i;
-            if (!KMAJOR) {
-                int row = u >> 3, c4 = u & 7;
-                *reinterpret_cast<float4*>(lds + row * KC_LD + c4 * 4) = regs[i];
-            } else {
-                int k = u / (ROWS / 4), m4 = u % (ROWS / 4);
-                *reinterpret_cast<float4*>(lds + k * ROWS + m4 * 4) = regs[i];
+    // loads the tile at k0 (for KGATHER: k0 must be the tile next_idx() was last called for)
+    __device__ __forceinline__ void load(int k0, int kend, int tid) {
+        if (!KMAJOR) {
+            r0 = *reinterpret_cast<const float4*>(p0 + k0);
+            if (UNITS > 1) r1 = *reinterpret_cast<const float4*>(p1 + k0);
+            if (UNITS > 2) {
+                r2 = *reinterpret_cast<const float4*>(p2 + k0);
+                r3 = *reinterpret_cast<const float4*>(p3 + k0);
             }
+        } else {
+            r0 = kload(0, k0, kend, tid, c0, col0_, n0_);
+            if (UNITS > 1) r1 = kload(1, k0, kend, tid, c1, col1_, n1_);
+            if (UNITS > 2) {
+                r2 = kload(2, k0, kend, tid, c2, col2_, n2_);
+                r3 = kload(3, k0, kend, tid, c3, col3_, n3_);
+            }
+        }
+    }
+    __device__ __forceinline__ static void store1(float* lds, int i, int tid, float4 v) {
+        int u = tid + 256 * i;
+        if (!KMAJOR) {
+            int row = u >> 3, c4 = u & 7;
+            *reinterpret_cast<float4*>(lds + row * KC_LD + c4 * 4) = v;
+        } else {
+            int k = u / (ROWS / 4), m4 = u % (ROWS / 4);
+            *reinterpret_cast<float4*>(lds + k * ROWS + m4 * 4) = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) {
+        store1(lds, 0, tid, r0);
+        if (UNITS > 1) store1(lds, 1, tid, r1);
+        if (UNITS > 2) {
+            store1(lds, 2, tid, r2);
+            store1(lds, 3, tid, r3);
         }
     }
 };
@@ -108,12 +185,12 @@ __device__ __forceinline__ float4 frag(const float* lds, int roff, int g, int la
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves");
-    using LA = TileLoader<BM, AKM>;
-    using LB = TileLoader<BN, BKM>;
+    using LA = TileLoader<BM, AKM, false>;  // only the B operand of a weight-gradient product is row-gathered along K
+    using LB = TileLoader<BN, BKM, KGATHER>;
     __shared__ __attribute__((aligned(16))) float lds[2 * (LA::LDS_ELEMS + LB::LDS_ELEMS)];
     constexpr int STAGE = LA::LDS_ELEMS + LB::LDS_ELEMS;  // one stage: A image then B image
 
@@ -136,19 +213,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     LA la; LB lb;
-    la.load(p.A, p.a_rows, p.lda, m0, p.M, kbeg, kend, tid);
-    lb.load(p.B, p.b_rows, p.ldb, n0, p.N, kbeg, kend, tid);
+    la.init(p.A, p.a_rows, p.lda, m0, p.M, tid);
+    lb.init(p.B, p.b_rows, p.ldb, n0, p.N, tid);
+    // tile(t) = kbeg + t*BK, clamped to a valid tile past the end (loaded, never used)
+    auto tile = [&](int t) { int k = kbeg + t * BK; return k < kend ? k : kbeg; };
+    lb.next_idx(tile(0), kend, tid);
+    la.load(tile(0), kend, tid);
+    lb.load(tile(0), kend, tid);
+    lb.next_idx(tile(1), kend, tid);
     la.store(lds, tid);
     lb.store(lds + LA::LDS_ELEMS, tid);
+    la.load(tile(1), kend, tid);
+    lb.load(tile(1), kend, tid);
+    lb.next_idx(tile(2), kend, tid);
     __syncthreads();
 
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        if (more) {
-            la.load(p.A, p.a_rows, p.lda, m0, p.M, k0 + BK, kend, tid);
-            lb.load(p.B, p.b_rows, p.ldb, n0, p.N, k0 + BK, kend, tid);
-        }
+    // Steady state of step k: MFMAs on LDS[cur] (tile k) | registers hold tile k+1, in flight
+    // since the END of step k-1 | after the MFMAs: registers -> LDS[cur^1], then the loads of
+    // tile k+2 are issued.  Issuing at the block end keeps the loads a whole step ahead of
+    // their consumer (hipcc sinks loads placed at the top of the step down to the LDS stores;
+    // a scheduling fence there demotes the staging registers to scratch).
+    int cur = 0, t = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, ++t) {
         const float* a_l = lds + cur * STAGE;
         const float* b_l = a_l + LA::LDS_ELEMS;
 #pragma unroll
@@ -168,10 +254,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) {
-            la.store(lds + (cur ^ 1) * STAGE, tid);
-            lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
-        }
+        la.store(lds + (cur ^ 1) * STAGE, tid);
+        lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
+        // fence: the loads below must not be hoisted above the LDS stores that read the same
+        // staging registers (hipcc then renames them and waits vmcnt(0) on copies at the block end)
+        __builtin_amdgcn_sched_barrier(0);
+        la.load(tile(t + 2), kend, tid);
+        lb.load(tile(t + 2), kend, tid);
+        lb.next_idx(tile(t + 3), kend, tid);
         __syncthreads();
         cur ^= 1;
     }
@@ -210,10 +300,13 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmParams& p, int akm, int bkm, hipStream_t s) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.split_k > 1 ? p.split_k : 1);
     dim3 block(256);
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
-    else return set_err(DVAE_ERR_ARG, "gemm: A K-major with B K-contiguous is not built");
+    const bool kg = bkm && p.b_rows != nullptr;
+    if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, p);
+    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, p);
+    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, false>), grid, block, 0, s, p);
+    else if (akm && bkm && kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, true>), grid, block, 0, s, p);
+    else return set_err(DVAE_ERR_ARG, "gemm: this operand layout / gather combination is not built");
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -229,6 +322,9 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     if (!d.b_kmajor) DVAE_REQUIRE(d.K % 32 == 0 && d.ldb >= d.K, "gemm: K-contiguous B needs K %% 32 == 0 (K=%d ldb=%d)", d.K, d.ldb);
     else DVAE_REQUIRE(d.N % 4 == 0 && d.ldb >= d.N, "gemm: K-major B needs N %% 4 == 0 (N=%d ldb=%d)", d.N, d.ldb);
     DVAE_REQUIRE(d.ldc >= d.N, "gemm: ldc < N");
+    // K-major operands are addressed with 32-bit byte offsets (buffer loads)
+    if (d.a_kmajor) DVAE_REQUIRE((double)d.K * d.lda * 4.0 < 4294967000.0, "gemm: K-major A operand exceeds 4 GiB");
+    if (d.b_kmajor && !d.b_rows) DVAE_REQUIRE((double)d.K * d.ldb * 4.0 < 4294967000.0, "gemm: K-major B operand exceeds 4 GiB");
     DVAE_REQUIRE(d.act >= 0 && d.act <= 2, "gemm: unknown activation %d", d.act);
 
     GemmParams p;

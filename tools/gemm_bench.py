@@ -1,0 +1,58 @@
+"""Micro-benchmark of dvae_gemm_f32 on the shapes of the train step (HIP events)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from _dvae_pkg import dvae_amd
+
+L = dvae_amd._lib
+lib = L.load()
+
+SHAPES = [
+    # (label, M, N, K, a_kmajor, b_kmajor, accumulate)
+    ("chain fwd GRU   ", 1024, 1536, 512, 0, 0, 0),
+    ("chain fwd gate  ", 1024, 1024, 512, 0, 0, 0),
+    ("chain bwd dGRU  ", 1024, 512, 1536, 0, 1, 1),
+    ("chain bwd dgate ", 1024, 512, 1024, 0, 1, 1),
+    ("EB fwd          ", 9251, 2048, 512, 0, 0, 0),
+    ("EA fwd          ", 7168, 2048, 512, 0, 0, 0),
+    ("V1 fwd          ", 7168, 1024, 512, 0, 0, 0),
+    ("dEB dgrad       ", 9251, 512, 2048, 0, 1, 1),
+    ("wgrad W1b       ", 2048, 512, 9251, 1, 1, 1),
+    ("wgrad Whh       ", 1536, 512, 8192, 1, 1, 1),
+    ("wgrad Wgm       ", 1024, 512, 8192, 1, 1, 1),
+    ("square 4096     ", 4096, 4096, 4096, 0, 0, 0),
+]
+
+
+def run(label, M, N, K, akm, bkm, acc, iters=20):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn((K, M) if akm else (M, K), device="cuda", generator=g)
+    B = torch.randn((K, N) if bkm else (N, K), device="cuda", generator=g)
+    Cm = torch.zeros(M, N, device="cuda")
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), N
+    d.M, d.N, d.K = M, N, K
+    d.a_kmajor, d.b_kmajor, d.accumulate = akm, bkm, acc
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+    for _ in range(3):
+        L.check(lib.dvae_gemm_f32(C.byref(d), sp))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        lib.dvae_gemm_f32(C.byref(d), sp)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / ms / 1e9
+    print("%s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s  (%4.1f%% of 157.3)" % (label, M, N, K, ms * 1e3, tf, tf / 1.573))
+
+
+if __name__ == "__main__":
+    for s in SHAPES:
+        run(*s)
