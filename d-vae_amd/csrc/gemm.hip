@@ -336,23 +336,28 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     if (d.K == 0) {
         // empty contraction: result is bias/act only; run with kend == 0
     }
-    // tile choice: big tiles when they fill the chip, small ones otherwise
+    // Tile and split-K choice.  The chip has 256 CUs x 4 SIMDs; a 128x128 tile keeps 4 waves
+    // busy for K/32 steps of 64 MFMAs, a 64x64 tile for K/32 steps of 16 MFMAs.  Products that
+    // accumulate into C (every dgrad / wgrad of the step) may split K across workgroups and
+    // combine with fp32 atomics; the split is chosen to put >= ~2 workgroups on every CU
+    // while keeping >= 4 K steps per workgroup.
     long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     long t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
     bool use128 = t128 >= 192 || (d.a_kmajor && t128 >= 24);
     int ksteps = cdiv(d.K, BK);
-    if (d.a_kmajor && d.b_kmajor && ksteps > 8 && d.accumulate && d.bias == nullptr && d.act == 0) {
-        // weight-gradient shape: long contraction, few output tiles -> split K
-        long tiles = use128 ? t128 : t64;
-        int want = (int)((1024 + tiles - 1) / tiles);
-        int maxsplit = ksteps / 4 > 0 ? ksteps / 4 : 1;
+    const bool small_m = d.M <= 32 && d.a_kmajor;
+    if (d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 8) {
+        long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
+        long target = use128 && !small_m ? 512 : 768;
+        int want = (int)((target + tiles - 1) / tiles);
+        int maxsplit = ksteps / 4;
         int sk = want < maxsplit ? want : maxsplit;
         if (sk > 1) {
             p.k_per_split = cdiv(ksteps, sk) * BK;
             p.split_k = cdiv(d.K, p.k_per_split);
         }
     }
-    if (d.M <= 32 && d.a_kmajor) return launch_cfg<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
+    if (small_m) return launch_cfg<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
     if (use128) return launch_cfg<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
     return launch_cfg<64, 64, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
 }

@@ -273,8 +273,12 @@ extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* 
     DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_x % 4 == 0 && seg_rows > 0, "segment_colsum: bad size");
     int segs = cdiv(rows, seg_rows);
     int w4 = width / 4;
-    int chunks = cdiv(seg_rows, 256);
-    if (chunks > 64) chunks = 64;
+    // enough row chunks to put >= 2 workgroups on every CU (each adds its partial with atomics)
+    int xblocks = cdiv(w4, 64);
+    int chunks = cdiv(seg_rows, 32);
+    int cap = cdiv(768, xblocks * segs);
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
     int rpc = cdiv(seg_rows, chunks);
     chunks = cdiv(seg_rows, rpc);
     hipLaunchKernelGGL(segment_colsum_kernel, dim3(cdiv(w4, 64), chunks, segs), dim3(256), 0, (hipStream_t)stream, out,

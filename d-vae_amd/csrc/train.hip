@@ -12,6 +12,7 @@
 #include "common.h"
 #include "model.h"
 #include "batch.h"
+#include <mutex>
 
 namespace dvae {
 
@@ -125,6 +126,43 @@ static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const in
     return gemm(g, s);
 }
 
+// ------------------------------------------------------------------ side stream
+// The two encoder directions are independent chains of small dependent launches
+// (a level's GEMM fills at most half the chip).  They run concurrently: direction 0 on
+// the caller's stream, direction 1 on a per-device non-blocking side stream, forked and
+// joined with events, so the function's contract (all work ordered on the caller's
+// stream when it returns) is unchanged.  Stream and events are created once per device.
+struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static int side_for_current_device(Side** out) {
+    static Side sides[64];
+    static std::mutex mu;
+    int dev = 0;
+    DVAE_HIP(hipGetDevice(&dev));
+    DVAE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Side& sd = sides[dev];
+    if (!sd.stream) {
+        DVAE_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+        DVAE_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+        DVAE_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+    }
+    *out = &sd;
+    return DVAE_OK;
+}
+static int fork_side(Side* sd, hipStream_t main) {
+    DVAE_HIP(hipEventRecord(sd->fork, main));
+    DVAE_HIP(hipStreamWaitEvent(sd->stream, sd->fork, 0));
+    return DVAE_OK;
+}
+static int join_side(Side* sd, hipStream_t main) {
+    DVAE_HIP(hipEventRecord(sd->join, sd->stream));
+    DVAE_HIP(hipStreamWaitEvent(main, sd->join, 0));
+    return DVAE_OK;
+}
+
 // ------------------------------------------------------------------ workspaces
 struct Bump {
     float* base;
@@ -141,7 +179,7 @@ struct EncWs {
     float *hg, *hgu, *out12;
     float* xoh;  // one-hot of vertex types [nB][Tp]
     // backward
-    float *dhs[2], *dmsg, *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt;
+    float *dhs[2], *dmsg[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
     float *d12, *dhgu, *dhg;
     size_t total;
 };
@@ -170,9 +208,9 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
         w.dgh[k] = on ? b.take(nB * 3 * Hp) : nullptr;
         w.dgin[k] = on ? b.take(nB * Hp) : nullptr;
         w.dagg[k] = on ? b.take(nB * Hp) : nullptr;
+        w.dmsg[k] = (on && !d.bn) ? b.take((size_t)c.B * Hp) : nullptr;
+        w.cnt[k] = (on && d.bn) ? b.take(nB * d.Tp) : nullptr;
     }
-    w.dmsg = d.bn ? nullptr : b.take((size_t)c.B * Hp);
-    w.cnt = d.bn ? b.take(nB * d.Tp) : nullptr;
     w.d12 = b.take((size_t)c.B * 2 * d.NZp);
     w.dhgu = b.take((size_t)c.B * Hp);
     w.dhg = b.take((size_t)c.B * 2 * Hp);
@@ -283,7 +321,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
     const int dirs = d.bidir ? 2 : 1;
 
-    for (int k = 0; k < dirs; ++k) {
+    auto run_dir = [&](int k, hipStream_t s) -> int {
         const int* off = k == 0 ? bv.pred_off : bv.succ_off;
         const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
         const float* whh = pw + L.whh[k];
@@ -292,7 +330,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
             DVAE_TRY(lin_fwd(w.agg[k], Hp, nullptr, whh, Hp, nullptr, w.gates[k], 3 * Hp, nB, 3 * Hp, Hp, 0, 0, s));
             DVAE_TRY(dvae_gru_pointwise_fwd(w.gates[k], pw + L.gi[k], bv.types, pw + L.bhn[k], w.agg[k], Hp, w.hs[k],
                                             Hp, w.ghn[k], nB, Hp, s));
-            continue;
+            return DVAE_OK;
         }
         for (int step = 0; step < n; ++step) {
             const int v = k == 0 ? step : n - 1 - step;
@@ -313,7 +351,16 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
                 DVAE_TRY(dvae_gated_pointwise_fwd(gm, pw + L.gv[k], w.msg[k] + r0 * Hp, Hp, B, Hp, (int)r0, B, s));
             }
         }
+        return DVAE_OK;
+    };
+    Side* side = nullptr;
+    if (dirs == 2) {
+        DVAE_TRY(side_for_current_device(&side));
+        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(run_dir(1, side->stream));
     }
+    DVAE_TRY(run_dir(0, s));
+    if (dirs == 2) DVAE_TRY(join_side(side, s));
     // graph state (models.py:704-718 / 1006-1027)
     DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
     const float* hgu = w.hg;
@@ -361,7 +408,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     }
     EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
 
-    for (int k = 0; k < dirs; ++k) {
+    auto run_dir = [&](int k, hipStream_t s) -> int {
         const float* whh = pw + L.whh[k];
         DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
         DVAE_TRY(dvae_scatter_rows_add_f32(w.dhs[k], Hp, dhg + (k ? Hp : 0), ld_dhg, k ? bv.hgb_off : bv.hgf_off,
@@ -373,8 +420,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             // d gtab[t] = sum over slots of (#neighbours of type t) * dagg[slot]
             const int* off = k == 0 ? bv.pred_off : bv.succ_off;
             const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
-            EW(count_kernel, (long)nB * d.Tp, w.cnt, off, idx, nB, d.Tp);
-            DVAE_TRY(lin_wgrad(w.cnt, d.Tp, w.dagg[k], Hp, nullptr, pg + L.gtab[k], Hp, nB, d.Tp, Hp, s));
+            EW(count_kernel, (long)nB * d.Tp, w.cnt[k], off, idx, nB, d.Tp);
+            DVAE_TRY(lin_wgrad(w.cnt[k], d.Tp, w.dagg[k], Hp, nullptr, pg + L.gtab[k], Hp, nB, d.Tp, Hp, s));
         } else {
             // transposed neighbour lists: messages of v went to its successors (fwd pass) / predecessors (bwd pass)
             const int* toff = k == 0 ? bv.succ_off : bv.pred_off;
@@ -385,8 +432,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                 const long r0 = (long)v * B;
                 float* dhs = w.dhs[k] + r0 * Hp;
                 if (step < n - 1) {
-                    DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg[k], Hp, toff + r0, tidx, B, Hp, 0, s));
-                    DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg, Hp, w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
+                    DVAE_TRY(dvae_gather_sum_f32(w.dmsg[k], Hp, w.dagg[k], Hp, toff + r0, tidx, B, Hp, 0, s));
+                    DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg[k], Hp, w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
                     DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
                 }
                 DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp,
@@ -399,7 +446,16 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
         DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s));
+        return DVAE_OK;
+    };
+    Side* side = nullptr;
+    if (dirs == 2) {
+        DVAE_TRY(side_for_current_device(&side));
+        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(run_dir(1, side->stream));
     }
+    DVAE_TRY(run_dir(0, s));
+    if (dirs == 2) DVAE_TRY(join_side(side, s));
     return DVAE_OK;
 }
 
