@@ -570,26 +570,33 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                            pw + L.be1, pw + L.we2, w.dl, g_res, w.dec, nullptr, c->CC, HEp,
                                            w.dw2_blocks, s));
     }
-    DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s));
-    DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s));
-    hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s, w.dl, c->NP, g_res, pg + L.be2);
-    DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s));
-    DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s));
+    // The predictors' weight gradients depend only on what is already computed; they run on the
+    // side stream while the main stream continues into the (latency-bound) state chain.
+    Side* side = nullptr;
+    DVAE_TRY(side_for_current_device(&side));
     DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
-    DVAE_TRY(lin_dgrad(w.dea, HEp, pw + L.w1a, Hp, w.dst, Hp, bv.rowsA, c->NA, HEp, Hp, 1, s));
-    DVAE_TRY(lin_dgrad(w.deb, HEp, pw + L.w1b, Hp, w.dst, Hp, bv.rowsB, c->NB, HEp, Hp, 1, s));
-    if (d.bn) {
-        DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s));
-        DVAE_TRY(lin_dgrad(w.dec, HEp, pw + L.w1c, Hp, w.dh0c, Hp, nullptr, B, HEp, Hp, 0, s));
-    }
-    // ---- vertex-type predictor -------------------------------------------------------
+    // vertex-type predictor, data path (main stream)
     EW(scaled_copy_kernel, (long)c->R * d.Tp, w.dlogits_s, w.dlogits, g_res, (long)c->R * d.Tp);
-    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s));
-    DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s));
     DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s));
     EW(relu_bwd_kernel, (long)c->R * d.HVp, w.dv1, w.v1, (long)c->R * d.HVp);
-    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv1, d.HVp, w.dv1, d.HVp, c->R, c->R, d.HVp, s));
-    DVAE_TRY(lin_wgrad(w.dv1, d.HVp, w.vs, Hp, nullptr, pg + L.wv1, Hp, c->R, d.HVp, Hp, s));
+    DVAE_TRY(fork_side(side, s));
+    {
+        hipStream_t s2 = side->stream;
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s2));
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
+        hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
+        DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2));
+        DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2));
+        if (d.bn) DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s2));
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s2));
+        DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s2));
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv1, d.HVp, w.dv1, d.HVp, c->R, c->R, d.HVp, s2));
+        DVAE_TRY(lin_wgrad(w.dv1, d.HVp, w.vs, Hp, nullptr, pg + L.wv1, Hp, c->R, d.HVp, Hp, s2));
+    }
+    // data path continues on the main stream
+    DVAE_TRY(lin_dgrad(w.dea, HEp, pw + L.w1a, Hp, w.dst, Hp, bv.rowsA, c->NA, HEp, Hp, 1, s));
+    DVAE_TRY(lin_dgrad(w.deb, HEp, pw + L.w1b, Hp, w.dst, Hp, bv.rowsB, c->NB, HEp, Hp, 1, s));
+    if (d.bn) DVAE_TRY(lin_dgrad(w.dec, HEp, pw + L.w1c, Hp, w.dh0c, Hp, nullptr, B, HEp, Hp, 0, s));
     DVAE_TRY(lin_dgrad(w.dv1, d.HVp, pw + L.wv1, Hp, w.dvs, Hp, nullptr, c->R, d.HVp, Hp, 0, s));
     DVAE_TRY(dvae_gather_sum_f32(w.dst, Hp, w.dvs, Hp, bv.vst_off, bv.vst_idx, nB, Hp, 1, s));
 
@@ -634,5 +641,6 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(lin_wgrad(w.dagg, Hp, w.z, d.NZp, nullptr, pg + L.fc3, d.NZp, B, Hp, d.NZp, s));
     DVAE_TRY(lin_dgrad(w.dagg, Hp, pw + L.fc3, d.NZp, w.dz, d.NZp, nullptr, B, Hp, d.NZp, 0, s));
     DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
+    DVAE_TRY(join_side(side, s));
     return DVAE_OK;
 }
