@@ -167,11 +167,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (Rehearsal on a 1-GPU box: DVAE_BENCH_BACKEND=gloo lets several ranks
+    # share device 0; the driver's runs use the default, nccl = RCCL over xGMI.)
+    backend = os.environ.get("DVAE_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     model = make_model(cfg).to(dev)
     model.train()
@@ -215,7 +222,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_val = float(last.item())

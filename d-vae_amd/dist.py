@@ -37,8 +37,15 @@ class GradSumReducer(object):
         self.flat.zero_()
 
     def all_reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self.flat.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal path (several ranks sharing one GPU): gloo reduces on the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)  # RCCL over xGMI when backend == "nccl"
 
     def nbytes(self):
         return self.flat.numel() * 4

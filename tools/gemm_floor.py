@@ -1,5 +1,5 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gemm_bench as g
-for (M,N,K) in [(64,64,512),(64,64,64),(1024,1024,64),(1024,1024,128),(1024,1024,256),(1024,1024,512),(1024,1024,1024),(1024,1024,2048),(2048,1024,512),(4096,1024,512),(512,512,512),(1024,2048,512)]:
-    g.run("floor", M, N, K, 0, 0, 0, iters=50)
+for (M,N,K) in [(8192,2048,128),(8192,2048,256),(8192,2048,512),(8192,2048,1024),(8192,2048,2048),(4096,2048,512),(2048,2048,512),(16384,2048,512)]:
+    g.run("big  ", M, N, K, 0, 0, 0, iters=20)
