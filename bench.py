@@ -32,6 +32,11 @@ sys.path.insert(0, ROOT)
 from _dvae_pkg import dvae_amd  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+# Memory-side traffic of one launch of the dominant GEMM on its cfg-2 shape (9251 x 2048 x 512),
+# from rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE 78394 KB, doubled per the gfx950
+# correction of MI355X_MICROARCH.md (section HBM), + WRITE_SIZE 74008 KB.  Infinity-Cache hits are
+# counted by these counters, so this is traffic behind L2, an upper bound on HBM bytes.
+MEASURED_TRAFFIC = {(9251, 2048, 512): (2 * 78394 + 74008) * 1024}
 
 CONFIGS = {
     # name: (class, ctor kwargs, per-GPU batch, generator)
@@ -247,7 +252,8 @@ def main():
                        "train_gflop_per_dag": train_flop_per_dag / 1e9, "grad_allreduce_mb": reducer.nbytes() / 1e6,
                        "pack_ms_per_batch": pack_ms, "loss_last_step": loss_val},
             "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["achieved"] / PEAK_F32_TFLOPS, "traffic": None, "kernel": roof["kernel"],
+                         "frac": roof["achieved"] / PEAK_F32_TFLOPS,
+                         "traffic": MEASURED_TRAFFIC.get(tuple(roof["shape"])), "kernel": roof["kernel"],
                          "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"]},
             "step_roofline": {"achieved": train_flop_per_dag * dags_per_s / world / 1e12, "peak": PEAK_F32_TFLOPS,
                               "unit": "TFLOP/s per GPU",

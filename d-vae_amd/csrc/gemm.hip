@@ -196,7 +196,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so workgroup ids that are equal mod 8 share an L2.  Give each such group a contiguous
+    // run of tiles (N fastest), so the tiles that re-read one A row block meet in one L2.
+    int m0, n0;
+    {
+        const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int orig = blockIdx.y * nx + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        m0 = (id / nx) * BM;
+        n0 = (id % nx) * BN;
+    }
     int kbeg = 0, kend = p.K;
     if (p.split_k > 1) {
         kbeg = blockIdx.z * p.k_per_split;
