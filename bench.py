@@ -224,6 +224,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i)
+    host_dt = time.perf_counter() - t0  # host time to ENQUEUE the steps (the GPU runs behind it)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -250,7 +251,8 @@ def main():
                                        cfg["max_n"], cfg["nvt"], B, " + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": world * B, "edges_per_dag": E, "outdeg_v0": od0,
                        "train_gflop_per_dag": train_flop_per_dag / 1e9, "grad_allreduce_mb": reducer.nbytes() / 1e6,
-                       "pack_ms_per_batch": pack_ms, "loss_last_step": loss_val},
+                       "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                       "loss_last_step": loss_val},
             "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["achieved"] / PEAK_F32_TFLOPS,
                          "traffic": MEASURED_TRAFFIC.get(tuple(roof["shape"])), "kernel": roof["kernel"],

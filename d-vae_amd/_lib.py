@@ -54,6 +54,8 @@ SIGNATURES = {
     "dvae_gru_pointwise_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dvae_gated_pointwise_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dvae_gated_pointwise_bwd": (_I, [_P, _I, _P, _P, _I, _I, _P]),
+    "dvae_gated_fwd_gather": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
+    "dvae_gated_bwd_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dvae_segment_colsum_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "dvae_pair_bce_fwd": (_I, [_P] * 12 + [_I, _I, _P]),
     "dvae_pair_bce_bwd_grouped": (_I, [_P] * 14 + [_I, _I, _I, _P]),

@@ -48,6 +48,10 @@ struct GemmParams {
 
 constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
+#ifndef DVAE_GEMM_MIDG
+#define DVAE_GEMM_MIDG 1
+#endif
+constexpr int MIDG = DVAE_GEMM_MIDG;  // k-group of a step after which the next tile is staged
 
 // Register-staged tile loader.  Everything that does not depend on the K step
 // (row gather, row clamping, column guards) is resolved ONCE in init(); the K loop
@@ -264,15 +268,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
+            if (g == MIDG) {
+                // mid-step: registers (tile k+1, in flight since the middle of step k-1) -> LDS[cur^1],
+                // then the loads of tile k+2 are issued: a whole step of MFMAs hides their latency.
+                la.store(lds + (cur ^ 1) * STAGE, tid);
+                lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
+                // fence: the loads below must not be hoisted above the LDS stores that read the same
+                // staging registers (hipcc then renames them and waits vmcnt(0) on copies at the block end)
+                __builtin_amdgcn_sched_barrier(0);
+                la.load(tile(t + 2), kend, tid);
+                lb.load(tile(t + 2), kend, tid);
+                lb.next_idx(tile(t + 3), kend, tid);
+            }
         }
-        la.store(lds + (cur ^ 1) * STAGE, tid);
-        lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
-        // fence: the loads below must not be hoisted above the LDS stores that read the same
-        // staging registers (hipcc then renames them and waits vmcnt(0) on copies at the block end)
-        __builtin_amdgcn_sched_barrier(0);
-        la.load(tile(t + 2), kend, tid);
-        lb.load(tile(t + 2), kend, tid);
-        lb.next_idx(tile(t + 3), kend, tid);
         __syncthreads();
         cur ^= 1;
     }

@@ -155,6 +155,63 @@ __global__ void gated_bwd_kernel(const float* __restrict__ dmsg, int ld_dmsg, co
     }
 }
 
+// gate/mapper pointwise part of the level at rows [cur_row0, cur_row0 + rows) fused with the
+// CSR gather-sum that feeds the NEXT level: both are independent per feature column, and every
+// source slot of graph b's next vertex lies in graph b, so the only not-yet-stored message a lane
+// needs is the one it has just computed (slot cur_row0 + b), which it keeps in registers.
+__global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __restrict__ gv, float* __restrict__ msg,
+                                        int ld_msg, int cur_row0, float* __restrict__ next_agg, int ld_agg,
+                                        const int* __restrict__ next_off, const int* __restrict__ idx, int rows,
+                                        int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        float* p = gm + (long)r * 2 * Hp;
+        float4 a = add4(ld4(p + c), ld4(gv + c));
+        float4 m = add4(ld4(p + Hp + c), ld4(gv + Hp + c));
+        float4 g = make_float4(1.f / (1.f + expf(-a.x)), 1.f / (1.f + expf(-a.y)), 1.f / (1.f + expf(-a.z)),
+                               1.f / (1.f + expf(-a.w)));
+        float4 own = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);
+        st4(p + c, g);
+        st4(p + Hp + c, m);
+        st4(msg + (long)(cur_row0 + r) * ld_msg + c, own);
+        if (next_agg) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = next_off[r]; k < next_off[r + 1]; ++k) {
+                int s = idx[k];
+                acc = add4(acc, s == cur_row0 + r ? own : ld4(msg + (long)s * ld_msg + c));
+            }
+            st4(next_agg + (long)r * ld_agg + c, acc);
+        }
+    }
+}
+
+// backward twin: d msg of a level = CSR gather-sum of the consumers' d agg rows (one or two lists),
+// consumed in registers by the gate/mapper pointwise backward; d msg itself is never stored.
+__global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, const int* __restrict__ off,
+                                        const int* __restrict__ idx, const float* __restrict__ dagg2,
+                                        const int* __restrict__ off2, const int* __restrict__ idx2,
+                                        const float* __restrict__ gm, float* __restrict__ dgm, int rows, int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = off[r]; k < off[r + 1]; ++k) d = add4(d, ld4(dagg + (long)idx[k] * ld + c));
+        if (off2)
+            for (int k = off2[r]; k < off2[r + 1]; ++k) d = add4(d, ld4(dagg2 + (long)idx2[k] * ld + c));
+        const float* p = gm + (long)r * 2 * Hp;
+        float4 g = ld4(p + c), m = ld4(p + Hp + c);
+        float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                                d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
+        float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        float* o = dgm + (long)r * 2 * Hp;
+        st4(o + c, dg);
+        st4(o + Hp + c, dm);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // out[seg][c] += sum_{rows of seg} x[row][c].  grid: (width/4/64, chunks, segs)
 __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__ out, int ld_out,
@@ -262,6 +319,35 @@ extern "C" int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, cons
     long total = (long)rows * (Hp / 4);
     hipLaunchKernelGGL(gated_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dmsg, ld_dmsg, gm,
                        dgm, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg, int32_t ld_msg, int32_t cur_row0,
+                                     float* next_agg, int32_t ld_agg, const int32_t* next_off, const int32_t* idx,
+                                     int32_t rows, int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(gm && gv_row && msg, "gated_fwd_gather: null pointer");
+    DVAE_REQUIRE(!next_agg || (next_off && idx), "gated_fwd_gather: the next level's CSR lists are missing");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_msg % 4 == 0 && (!next_agg || ld_agg % 4 == 0) && cur_row0 >= 0,
+                 "gated_fwd_gather: bad size");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gated_fwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gm, gv_row, msg,
+                       ld_msg, cur_row0, next_agg, ld_agg, next_off, idx, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx,
+                                     const float* dagg2, const int32_t* off2, const int32_t* idx2, const float* gm,
+                                     float* dgm, int32_t rows, int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(dagg && off && idx && gm && dgm, "gated_bwd_gather: null pointer");
+    DVAE_REQUIRE(!off2 || (dagg2 && idx2), "gated_bwd_gather: second list incomplete");
+    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld % 4 == 0, "gated_bwd_gather: bad size");
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gated_bwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dagg, ld, off,
+                       idx, dagg2, off2, idx2, gm, dgm, rows, Hp);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

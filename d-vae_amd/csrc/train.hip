@@ -179,7 +179,7 @@ struct EncWs {
     float *hg, *hgu, *out12;
     float* xoh;  // one-hot of vertex types [nB][Tp]
     // backward
-    float *dhs[2], *dmsg[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
+    float *dhs[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
     float *d12, *dhgu, *dhg;
     size_t total;
 };
@@ -208,7 +208,6 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
         w.dgh[k] = on ? b.take(nB * 3 * Hp) : nullptr;
         w.dgin[k] = on ? b.take(nB * Hp) : nullptr;
         w.dagg[k] = on ? b.take(nB * Hp) : nullptr;
-        w.dmsg[k] = (on && !d.bn) ? b.take((size_t)c.B * Hp) : nullptr;
         w.cnt[k] = (on && d.bn) ? b.take(nB * d.Tp) : nullptr;
     }
     w.d12 = b.take((size_t)c.B * 2 * d.NZp);
@@ -222,7 +221,7 @@ struct DecWs {
     float *z, *agg, *gates, *ghn, *st, *gm, *msg;
     float *ea, *eb, *ec, *dl, *vs, *v1, *logits, *dlogits, *sums, *xoh, *cnt;
     // backward
-    float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dmsg, *dgm, *dh0c, *dz, *gs;
+    float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dgm, *dh0c, *dz, *gs;
     int dw2_blocks;
     size_t total;
 };
@@ -260,7 +259,6 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dgh = b.take(NST * 3 * Hp);
     w.dgin = b.take(NST * Hp);
     w.dagg = b.take(NST * Hp);
-    w.dmsg = d.bn ? nullptr : b.take((size_t)c.B * Hp);
     w.dgm = d.bn ? nullptr : b.take(nB * 2 * Hp);
     w.dh0c = d.bn ? b.take((size_t)c.B * Hp) : nullptr;
     w.dz = b.take((size_t)c.B * d.NZp);
@@ -321,45 +319,59 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
     const int dirs = d.bidir ? 2 : 1;
 
-    auto run_dir = [&](int k, hipStream_t s) -> int {
+    // DVAE_BN has no recurrence: each direction is one batched pass over all levels.
+    auto run_dir_bn = [&](int k, hipStream_t s) -> int {
         const int* off = k == 0 ? bv.pred_off : bv.succ_off;
         const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
-        const float* whh = pw + L.whh[k];
-        if (d.bn) {
-            DVAE_TRY(dvae_gather_sum_f32(w.agg[k], Hp, pw + L.gtab[k], Hp, off, idx, nB, Hp, 0, s));
-            DVAE_TRY(lin_fwd(w.agg[k], Hp, nullptr, whh, Hp, nullptr, w.gates[k], 3 * Hp, nB, 3 * Hp, Hp, 0, 0, s));
-            DVAE_TRY(dvae_gru_pointwise_fwd(w.gates[k], pw + L.gi[k], bv.types, pw + L.bhn[k], w.agg[k], Hp, w.hs[k],
-                                            Hp, w.ghn[k], nB, Hp, s));
-            return DVAE_OK;
+        DVAE_TRY(dvae_gather_sum_f32(w.agg[k], Hp, pw + L.gtab[k], Hp, off, idx, nB, Hp, 0, s));
+        DVAE_TRY(lin_fwd(w.agg[k], Hp, nullptr, pw + L.whh[k], Hp, nullptr, w.gates[k], 3 * Hp, nB, 3 * Hp, Hp, 0, 0, s));
+        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates[k], pw + L.gi[k], bv.types, pw + L.bhn[k], w.agg[k], Hp, w.hs[k],
+                                        Hp, w.ghn[k], nB, Hp, s));
+        return DVAE_OK;
+    };
+    // One level of one direction of the DVAE chain: GRU (hidden product + pointwise), then the
+    // gate/mapper product whose pointwise tail also gathers the next level's predecessor sum.
+    auto level = [&](int k, int step, hipStream_t s) -> int {
+        const int* off = k == 0 ? bv.pred_off : bv.succ_off;
+        const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+        const int v = k == 0 ? step : n - 1 - step;
+        const long r0 = (long)v * B;
+        float* agg = w.agg[k] + r0 * Hp;
+        float* gates = w.gates[k] + r0 * 3 * Hp;
+        if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0
+            DVAE_HIP(hipMemsetAsync(agg, 0, sizeof(float) * (size_t)B * Hp, s));
+            DVAE_HIP(hipMemsetAsync(gates, 0, sizeof(float) * (size_t)B * 3 * Hp, s));
+        } else {
+            DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
         }
-        for (int step = 0; step < n; ++step) {
-            const int v = k == 0 ? step : n - 1 - step;
-            const long r0 = (long)v * B;
-            float* agg = w.agg[k] + r0 * Hp;
-            float* gates = w.gates[k] + r0 * 3 * Hp;
-            DVAE_TRY(dvae_gather_sum_f32(agg, Hp, w.msg[k], Hp, off + r0, idx, B, Hp, 0, s));
-            if (step == 0) {
-                DVAE_HIP(hipMemsetAsync(gates, 0, sizeof(float) * (size_t)B * 3 * Hp, s));
-            } else {
-                DVAE_TRY(lin_fwd(agg, Hp, nullptr, whh, Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
-            }
-            DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp,
-                                            w.hs[k] + r0 * Hp, Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
-            if (step < n - 1) {
-                float* gm = w.gm[k] + r0 * 2 * Hp;
-                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
-                DVAE_TRY(dvae_gated_pointwise_fwd(gm, pw + L.gv[k], w.msg[k] + r0 * Hp, Hp, B, Hp, (int)r0, B, s));
-            }
+        DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp, w.hs[k] + r0 * Hp,
+                                        Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
+        if (step < n - 1) {
+            const long r1 = (long)(k == 0 ? v + 1 : v - 1) * B;
+            float* gm = w.gm[k] + r0 * 2 * Hp;
+            DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+            DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0,
+                                           w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
         }
         return DVAE_OK;
     };
+    // The two directions are independent chains of small dependent launches; they run on two
+    // streams and are ENQUEUED level by level in turn, so that neither stream starves while the
+    // host is still issuing the other one's launches.
     Side* side = nullptr;
     if (dirs == 2) {
         DVAE_TRY(side_for_current_device(&side));
         DVAE_TRY(fork_side(side, s));
-        DVAE_TRY(run_dir(1, side->stream));
     }
-    DVAE_TRY(run_dir(0, s));
+    if (d.bn) {
+        if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
+        DVAE_TRY(run_dir_bn(0, s));
+    } else {
+        for (int step = 0; step < n; ++step) {
+            if (dirs == 2) DVAE_TRY(level(1, step, side->stream));
+            DVAE_TRY(level(0, step, s));
+        }
+    }
     if (dirs == 2) DVAE_TRY(join_side(side, s));
     // graph state (models.py:704-718 / 1006-1027)
     DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
@@ -408,53 +420,71 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     }
     EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
 
-    auto run_dir = [&](int k, hipStream_t s) -> int {
-        const float* whh = pw + L.whh[k];
+    auto begin_dir = [&](int k, hipStream_t s) -> int {
         DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
         DVAE_TRY(dvae_scatter_rows_add_f32(w.dhs[k], Hp, dhg + (k ? Hp : 0), ld_dhg, k ? bv.hgb_off : bv.hgf_off,
                                            k ? bv.hgb_idx : bv.hgf_idx, B, Hp, s));
-        if (d.bn) {
-            DVAE_TRY(dvae_gru_pointwise_bwd(w.dhs[k], Hp, w.gates[k], w.ghn[k], w.agg[k], Hp, w.dgh[k], w.dgin[k],
-                                            w.dagg[k], Hp, nB, Hp, s));
-            DVAE_TRY(lin_dgrad(w.dgh[k], 3 * Hp, whh, Hp, w.dagg[k], Hp, nullptr, nB, 3 * Hp, Hp, 1, s));
-            // d gtab[t] = sum over slots of (#neighbours of type t) * dagg[slot]
-            const int* off = k == 0 ? bv.pred_off : bv.succ_off;
-            const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
-            EW(count_kernel, (long)nB * d.Tp, w.cnt[k], off, idx, nB, d.Tp);
-            DVAE_TRY(lin_wgrad(w.cnt[k], d.Tp, w.dagg[k], Hp, nullptr, pg + L.gtab[k], Hp, nB, d.Tp, Hp, s));
-        } else {
-            // transposed neighbour lists: messages of v went to its successors (fwd pass) / predecessors (bwd pass)
-            const int* toff = k == 0 ? bv.succ_off : bv.pred_off;
-            const int* tidx = k == 0 ? bv.succ_idx : bv.pred_idx;
-            DVAE_HIP(hipMemsetAsync(w.dgm[k], 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
-            for (int step = n - 1; step >= 0; --step) {
-                const int v = k == 0 ? step : n - 1 - step;
-                const long r0 = (long)v * B;
-                float* dhs = w.dhs[k] + r0 * Hp;
-                if (step < n - 1) {
-                    DVAE_TRY(dvae_gather_sum_f32(w.dmsg[k], Hp, w.dagg[k], Hp, toff + r0, tidx, B, Hp, 0, s));
-                    DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg[k], Hp, w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
-                    DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
-                }
-                DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp,
-                                                w.agg[k] + r0 * Hp, Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp,
-                                                w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
-                if (step > 0)
-                    DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
-            }
+        if (!d.bn) DVAE_HIP(hipMemsetAsync(w.dgm[k], 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
+        return DVAE_OK;
+    };
+    auto run_dir_bn = [&](int k, hipStream_t s) -> int {
+        DVAE_TRY(dvae_gru_pointwise_bwd(w.dhs[k], Hp, w.gates[k], w.ghn[k], w.agg[k], Hp, w.dgh[k], w.dgin[k],
+                                        w.dagg[k], Hp, nB, Hp, s));
+        DVAE_TRY(lin_dgrad(w.dgh[k], 3 * Hp, pw + L.whh[k], Hp, w.dagg[k], Hp, nullptr, nB, 3 * Hp, Hp, 1, s));
+        // d gtab[t] = sum over slots of (#neighbours of type t) * dagg[slot]
+        const int* off = k == 0 ? bv.pred_off : bv.succ_off;
+        const int* idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+        EW(count_kernel, (long)nB * d.Tp, w.cnt[k], off, idx, nB, d.Tp);
+        DVAE_TRY(lin_wgrad(w.cnt[k], d.Tp, w.dagg[k], Hp, nullptr, pg + L.gtab[k], Hp, nB, d.Tp, Hp, s));
+        return DVAE_OK;
+    };
+    // one level of the reverse chain.  Messages of v went to its successors (forward pass) /
+    // predecessors (backward pass): the transposed lists gather their d agg rows.
+    auto level = [&](int k, int step, hipStream_t s) -> int {
+        const int* toff = k == 0 ? bv.succ_off : bv.pred_off;
+        const int* tidx = k == 0 ? bv.succ_idx : bv.pred_idx;
+        const int v = k == 0 ? step : n - 1 - step;
+        const long r0 = (long)v * B;
+        float* dhs = w.dhs[k] + r0 * Hp;
+        if (step < n - 1) {
+            DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr,
+                                           w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
+            DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+        }
+        DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
+                                        w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
+        if (step > 0)
+            DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
+                               3 * Hp, Hp, 1, s));
+        return DVAE_OK;
+    };
+    auto end_dir = [&](int k, hipStream_t s) -> int {
+        if (!d.bn) {
             DVAE_TRY(lin_wgrad(w.dgm[k], 2 * Hp, w.hs[k], Hp, nullptr, pg + L.wgm[k], Hp, nB, 2 * Hp, Hp, s));
             DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
         DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s));
         return DVAE_OK;
     };
+    // as in the forward pass: two streams, enqueued level by level in turn
     Side* side = nullptr;
     if (dirs == 2) {
         DVAE_TRY(side_for_current_device(&side));
         DVAE_TRY(fork_side(side, s));
-        DVAE_TRY(run_dir(1, side->stream));
+        DVAE_TRY(begin_dir(1, side->stream));
     }
-    DVAE_TRY(run_dir(0, s));
+    DVAE_TRY(begin_dir(0, s));
+    if (d.bn) {
+        if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
+        DVAE_TRY(run_dir_bn(0, s));
+    } else {
+        for (int step = n - 1; step >= 0; --step) {
+            if (dirs == 2) DVAE_TRY(level(1, step, side->stream));
+            DVAE_TRY(level(0, step, s));
+        }
+    }
+    if (dirs == 2) DVAE_TRY(end_dir(1, side->stream));
+    DVAE_TRY(end_dir(0, s));
     if (dirs == 2) DVAE_TRY(join_side(side, s));
     return DVAE_OK;
 }
@@ -500,7 +530,6 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
         for (int v = 0; v < n; ++v) {
             const long r0 = (long)v * B;
             if (v > 0) {
-                DVAE_TRY(dvae_gather_sum_f32(w.agg + r0 * Hp, Hp, w.msg, Hp, bv.pred_off + r0, bv.pred_idx, B, Hp, 0, s));
                 DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
                 DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
                                                 w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, B, Hp, s));
@@ -508,7 +537,9 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
             if (v < n - 1) {
                 float* gm = w.gm + r0 * 2 * Hp;
                 DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
-                DVAE_TRY(dvae_gated_pointwise_fwd(gm, pw + L.gv[0], w.msg + r0 * Hp, Hp, B, Hp, (int)r0, B, s));
+                // pointwise tail + predecessor sum of vertex v + 1
+                DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0,
+                                               w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp, s));
             }
         }
         // partial states: non-recurrent, one batched pass
@@ -622,9 +653,10 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
             if (v < n - 1) {
-                DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, B, Hp, 0, s));
-                DVAE_TRY(dvae_gather_sum_f32(w.dmsg, Hp, w.dagg + p0 * Hp, Hp, bv.pt_off + r0, bv.pt_idx, B, Hp, 1, s));
-                DVAE_TRY(dvae_gated_pointwise_bwd(w.dmsg, Hp, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B, Hp, s));
+                // d msg = consumers' d agg (successor slots + partial rows), used in registers
+                DVAE_TRY(dvae_gated_bwd_gather(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp,
+                                               bv.pt_off + r0, bv.pt_idx, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B,
+                                               Hp, s));
                 DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
             }
             DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,

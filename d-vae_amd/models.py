@@ -188,16 +188,29 @@ class DVAE(nn.Module):
         self._n_packed = None
         self._pw = None
         self._pw_key = None
+        self._named_cache = None
         self._enc_names = _ENC_FWD + (_ENC_BWD if self.bidir else [])
         self._dec_names = list(_DEC)
         self.eps_override = None  # test hook: fixed normal draw for reparameterize
 
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            self.__dict__["_named_cache"] = None  # a (re)assigned sub-module changes the parameter set
+        super(DVAE, self).__setattr__(name, value)
+
+    def _named(self):
+        """name -> Parameter, cached (walking the module tree costs ~100 us per call, several
+        times per step); dropped when modules are converted / re-assigned."""
+        if self._named_cache is None:
+            self._named_cache = dict(self.named_parameters())
+        return self._named_cache
+
     def _param_table(self):
-        named = dict(self.named_parameters())
+        named = self._named()
         return [named.get(k) for k in PARAM_NAMES]
 
     def _hot_params(self, names):
-        named = dict(self.named_parameters())
+        named = self._named()
         return [named[k] for k in names]
 
     def _packed_weights(self):
@@ -225,7 +238,7 @@ class DVAE(nn.Module):
 
     def _unpack(self, pw, pg, names):
         lib = _lib.load()
-        named = dict(self.named_parameters())
+        named = self._named()
         ptrs = [None] * _lib.NUM_PARAMS
         want = [0] * _lib.NUM_PARAMS
         grads = []
@@ -257,6 +270,7 @@ class DVAE(nn.Module):
     def _apply(self, fn, *a, **kw):
         self.device = None
         self._pw = None
+        self._named_cache = None
         return super(DVAE, self)._apply(fn, *a, **kw)
 
     def _collate_fn(self, G):

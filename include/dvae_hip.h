@@ -92,6 +92,22 @@ int dvae_gated_pointwise_fwd(float* gm, const float* gv, float* msg, int32_t ld_
 int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, const float* gm, float* dgm, int32_t rows,
                              int32_t Hp, void* stream);
 
+/* The same forward pointwise part for the level stored at rows [cur_row0,
+ * cur_row0 + rows) of msg, fused with the gather-sum of models.py:661-669 for the
+ * NEXT level of the pass: next_agg[r] = sum_{k in [next_off[r], next_off[r+1])}
+ * msg[idx[k]] (next_agg NULL: pointwise part only).  gm / gv_row point at the
+ * current level's rows / vertex-id row.  A listed source slot that lies in the
+ * current level must be cur_row0 + r (the same graph's vertex), which holds for
+ * the packer's CSR lists; it is taken from registers. */
+int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg, int32_t ld_msg, int32_t cur_row0,
+                          float* next_agg, int32_t ld_agg, const int32_t* next_off, const int32_t* idx, int32_t rows,
+                          int32_t Hp, void* stream);
+/* Backward twin: d msg[r] = sum of dagg[idx[k]] over list 1 (+ dagg2[idx2[k]] over
+ * the optional list 2), fed straight into the pointwise backward -> dgm. */
+int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx, const float* dagg2,
+                          const int32_t* off2, const int32_t* idx2, const float* gm, float* dgm, int32_t rows,
+                          int32_t Hp, void* stream);
+
 /* out[seg][0:width] += sum over the seg_rows rows of segment seg of x */
 int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                             int32_t seg_rows, int32_t width, void* stream);

@@ -256,3 +256,63 @@ def test_vertex_ce_matches_torch():
                                     dlog.data_ptr(), lsum.data_ptr(), R, T, Tp, _s()))
     assert abs(lsum.item() - ref.item()) < 1e-4 * abs(ref.item())
     assert (dlog[:, :T] - lg.grad).abs().max() < 1e-5 and dlog[:, T:].abs().max() == 0
+
+
+def test_gated_fused_gather_kernels_match_unfused():
+    """gate/mapper pointwise part fused with the neighbouring CSR gather-sum (forward: next
+    level's predecessor sum; backward: d msg from the consumers' d agg) == the two-kernel
+    sequence, bit for bit (same fp32 operations in the same order)."""
+    g = torch.Generator().manual_seed(11)
+    B, Hp, levels = 50, 64, 4
+    lib = L.load()
+    msg = torch.randn(levels * B, Hp, generator=g).cuda()
+    cur = 2  # current level; its rows of msg are overwritten by the kernel
+    gm0 = torch.randn(B, 2 * Hp, generator=g).cuda()
+    gv = torch.randn(levels, 2 * Hp, generator=g).cuda()
+    # next level's predecessor lists: slots of the same graph in levels <= cur
+    off = [0]
+    idx = []
+    for b in range(B):
+        ks = [u for u in range(cur + 1) if torch.rand((), generator=g) < 0.6]
+        idx += [u * B + b for u in ks]
+        off.append(len(idx))
+    off_d = torch.tensor(off, dtype=torch.int32).cuda()
+    idx_d = torch.tensor(idx + [0], dtype=torch.int32).cuda()
+    # reference: unfused pair
+    gm_ref, msg_ref = gm0.clone(), msg.clone()
+    L.check(lib.dvae_gated_pointwise_fwd(gm_ref.data_ptr(), gv.data_ptr(), msg_ref[cur * B:].data_ptr(), Hp, B, Hp,
+                                         cur * B, B, _s()))
+    agg_ref = torch.full((B, Hp), float("nan")).cuda()
+    L.check(lib.dvae_gather_sum_f32(agg_ref.data_ptr(), Hp, msg_ref.data_ptr(), Hp, off_d.data_ptr(), idx_d.data_ptr(),
+                                    B, Hp, 0, _s()))
+    gm_f, msg_f = gm0.clone(), msg.clone()
+    agg_f = torch.full((B, Hp), float("nan")).cuda()
+    L.check(lib.dvae_gated_fwd_gather(gm_f.data_ptr(), gv[cur].data_ptr(), msg_f.data_ptr(), Hp, cur * B,
+                                      agg_f.data_ptr(), Hp, off_d.data_ptr(), idx_d.data_ptr(), B, Hp, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(gm_f, gm_ref) and torch.equal(msg_f, msg_ref) and torch.equal(agg_f, agg_ref)
+    # against plain torch
+    a = gm0[:, :Hp] + gv[cur, :Hp]
+    m = gm0[:, Hp:] + gv[cur, Hp:]
+    assert (msg_f[cur * B:(cur + 1) * B] - torch.sigmoid(a) * m).abs().max() < 1e-6
+    # backward twin: two lists
+    dagg = torch.randn(levels * B, Hp, generator=g).cuda()
+    dagg2 = torch.randn(30, Hp, generator=g).cuda()
+    lens2 = torch.randint(0, 3, (B,), generator=g)
+    off2 = torch.zeros(B + 1, dtype=torch.int32)
+    off2[1:] = lens2.cumsum(0)
+    idx2 = torch.randint(0, 30, (int(off2[-1]) + 1,), generator=g).int()
+    off2_d, idx2_d = off2.cuda(), idx2.cuda()
+    dmsg = torch.zeros(B, Hp).cuda()
+    L.check(lib.dvae_gather_sum_f32(dmsg.data_ptr(), Hp, dagg.data_ptr(), Hp, off_d.data_ptr(), idx_d.data_ptr(),
+                                    B, Hp, 0, _s()))
+    L.check(lib.dvae_gather_sum_f32(dmsg.data_ptr(), Hp, dagg2.data_ptr(), Hp, off2_d.data_ptr(), idx2_d.data_ptr(),
+                                    B, Hp, 1, _s()))
+    dgm_ref = torch.zeros(B, 2 * Hp).cuda()
+    L.check(lib.dvae_gated_pointwise_bwd(dmsg.data_ptr(), Hp, gm_ref.data_ptr(), dgm_ref.data_ptr(), B, Hp, _s()))
+    dgm_f = torch.zeros(B, 2 * Hp).cuda()
+    L.check(lib.dvae_gated_bwd_gather(dagg.data_ptr(), Hp, off_d.data_ptr(), idx_d.data_ptr(), dagg2.data_ptr(),
+                                      off2_d.data_ptr(), idx2_d.data_ptr(), gm_ref.data_ptr(), dgm_f.data_ptr(), B, Hp,
+                                      _s()))
+    torch.cuda.synchronize()
+    assert (dgm_f - dgm_ref).abs().max() < 1e-6
