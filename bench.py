@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from _dvae_pkg import dvae_amd  # noqa: E402
 
-PEAK_F32_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3    # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # Memory-side traffic of one launch of the dominant GEMM on its cfg-2 shape (9251 x 2048 x 512),
 # from rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE 78394 KB, doubled per the gfx950
 # correction of MI355X_MICROARCH.md (section HBM), + WRITE_SIZE 74008 KB.  Infinity-Cache hits are
@@ -44,22 +45,26 @@ CONFIGS = {
     "cfg2": dict(cls="DVAE", max_n=8, nvt=8, hs=501, nz=56, bidir=True, B=1024, kind="enas", layers=6, ntypes=6),
     "cfg3": dict(cls="DVAE_BN", max_n=10, nvt=10, hs=501, nz=56, bidir=False, B=4096, kind="bn", layers=8, ntypes=8),
     "cfg4": dict(cls="DVAE", max_n=14, nvt=8, hs=501, nz=56, bidir=True, B=1024, kind="enas", layers=12, ntypes=6),
+    # 64-vertex synthetic DAGs: layer i takes an optional edge from j < i with probability min(0.30, 3 / i)
+    "cfg5": dict(cls="DVAE", max_n=64, nvt=18, hs=1024, nz=56, bidir=True, B=2048, kind="enas", layers=62, ntypes=16,
+                 sparse=True, n_batches=2),
 }
 
 
 def make_graphs(cfg, count, seed):
     if cfg["kind"] == "enas":
-        rows = dvae_amd.data.synth_enas_rows(count, cfg["layers"], cfg["ntypes"], 0.30, seed)
+        p_rule = (lambda i: min(0.30, 3.0 / i) if i > 0 else 0.0) if cfg.get("sparse") else None
+        rows = dvae_amd.data.synth_enas_rows(count, cfg["layers"], cfg["ntypes"], 0.30, seed, p_rule)
         return dvae_amd.data.enas_rows_to_arrays(rows, cfg["max_n"])
     rows = dvae_amd.data.synth_bn_rows(count, cfg["layers"], 0.25, seed)
     return dvae_amd.data.bn_rows_to_arrays(rows, cfg["max_n"])
 
 
-def make_model(cfg, seed=1):
+def make_model(cfg, seed=1, mfma_dtype="fp32"):
     torch.manual_seed(seed)
     if cfg["cls"] == "DVAE":
-        return dvae_amd.DVAE(cfg["max_n"], cfg["nvt"], 0, 1, cfg["hs"], cfg["nz"], cfg["bidir"])
-    return dvae_amd.DVAE_BN(cfg["max_n"], cfg["nvt"], 0, 1, cfg["hs"], cfg["nz"], cfg["bidir"])
+        return dvae_amd.DVAE(cfg["max_n"], cfg["nvt"], 0, 1, cfg["hs"], cfg["nz"], cfg["bidir"], mfma_dtype=mfma_dtype)
+    return dvae_amd.DVAE_BN(cfg["max_n"], cfg["nvt"], 0, 1, cfg["hs"], cfg["nz"], cfg["bidir"], mfma_dtype=mfma_dtype)
 
 
 def f_alg_macs(cfg, ga):
@@ -81,7 +86,7 @@ def f_alg_macs(cfg, ga):
     return gru + gm + vert + edge + head, float(E), float(od0)
 
 
-def time_dominant_gemm(cfg, batch, iters=30):
+def time_dominant_gemm(cfg, batch, iters=30, bf16=False):
     """HIP-event timing of the fp32 MFMA GEMM on the largest product of the step:
     the edge predictor's first layer over all distinct 'current vertex' states
     (EB = ST[rowsB] W1b^T: M = NB rows, N = HEp, K = Hp)."""
@@ -100,17 +105,19 @@ def time_dominant_gemm(cfg, batch, iters=30):
     d.M, d.N, d.K = M, HEp, Hp
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
+    fn = lib.dvae_gemm_bf16 if bf16 else lib.dvae_gemm_f32
     for _ in range(3):
-        dvae_amd._lib.check(lib.dvae_gemm_f32(C.byref(d), sp))
+        dvae_amd._lib.check(fn(C.byref(d), sp))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):
-        lib.dvae_gemm_f32(C.byref(d), sp)
+        fn(C.byref(d), sp)
     e1.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * HEp * Hp
-    return dict(kernel="gemm_f32_kernel<128,128> (v_mfma_f32_32x32x2_f32)", shape=[M, HEp, Hp],
+    return dict(kernel="gemm_bf16_kernel<128,128> (v_mfma_f32_32x32x16_bf16)" if bf16 else
+                "gemm_f32_kernel<128,128> (v_mfma_f32_32x32x2_f32)", shape=[M, HEp, Hp],
                 avg_ms=ms, achieved=flops / (ms * 1e-3) / 1e12)
 
 
@@ -158,6 +165,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-unit input type: f32 = the parity mode (headline); bf16 = reduced precision, "
+                         "reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -185,14 +195,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    model = make_model(cfg).to(dev)
+    bf16 = args.dtype == "bf16"
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+    model = make_model(cfg, mfma_dtype="bf16" if bf16 else "fp32").to(dev)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)  # same update rule, one multi-tensor launch
     reducer = dvae_amd.dist.GradSumReducer(model)
 
     # pre-packed batches: weak scaling, every rank owns B graphs per step
     B = cfg["B"]
-    n_batches = 4
+    n_batches = cfg.get("n_batches", 4)
     t0 = time.perf_counter()
     batches = []
     for i in range(n_batches):
@@ -237,29 +249,30 @@ def main():
         macs, E, od0 = f_alg_macs(cfg, batches[0].arrays)
         train_flop_per_dag = 6.0 * macs
         dags_per_s = world * B * args.steps / dt
-        roof = time_dominant_gemm(cfg, batches[0])
+        roof = time_dominant_gemm(cfg, batches[0], bf16=bf16)
         out = {
             "metric": "DAGs/sec train step (ENAS6, hs=501)" if args.config in ("cfg1", "cfg2") else
                       "DAGs/sec train step (%s)" % args.config,
             "value": dags_per_s, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s%s hs=%d nz=%d on synthetic %s DAGs (n=%d, nvt=%d), %d DAGs per GPU per step, "
-                                   "full train step incl. Adam%s" % (
+                                   "full train step incl. Adam%s%s" % (
                                        args.config, cfg["cls"], " bidirectional" if cfg["bidir"] else "", cfg["hs"],
                                        cfg["nz"], "ENAS-%d" % cfg["layers"] if cfg["kind"] == "enas" else "asia-shape BN",
-                                       cfg["max_n"], cfg["nvt"], B, " + RCCL grad all-reduce" if world > 1 else ""),
+                                       cfg["max_n"], cfg["nvt"], B, " + RCCL grad all-reduce" if world > 1 else "",
+                                       "; bf16 MFMA inputs, fp32 accumulate / weights / activations" if bf16 else ""),
                        "global_batch": world * B, "edges_per_dag": E, "outdeg_v0": od0,
                        "train_gflop_per_dag": train_flop_per_dag / 1e9, "grad_allreduce_mb": reducer.nbytes() / 1e6,
                        "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                        "loss_last_step": loss_val},
-            "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["achieved"] / PEAK_F32_TFLOPS,
-                         "traffic": MEASURED_TRAFFIC.get(tuple(roof["shape"])), "kernel": roof["kernel"],
+            "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": roof["achieved"] / peak,
+                         "traffic": None if bf16 else MEASURED_TRAFFIC.get(tuple(roof["shape"])), "kernel": roof["kernel"],
                          "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"]},
-            "step_roofline": {"achieved": train_flop_per_dag * dags_per_s / world / 1e12, "peak": PEAK_F32_TFLOPS,
+            "step_roofline": {"achieved": train_flop_per_dag * dags_per_s / world / 1e12, "peak": peak,
                               "unit": "TFLOP/s per GPU",
-                              "frac": train_flop_per_dag * dags_per_s / world / 1e12 / PEAK_F32_TFLOPS},
+                              "frac": train_flop_per_dag * dags_per_s / world / 1e12 / peak},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

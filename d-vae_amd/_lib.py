@@ -14,7 +14,7 @@ NUM_PARAMS = 36
 
 class ModelDesc(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
-                ("max_n", "nvt", "hs", "nz", "bidir", "vid", "is_bn", "start_type", "end_type")]
+                ("max_n", "nvt", "hs", "nz", "bidir", "vid", "is_bn", "start_type", "end_type", "mfma_bf16")]
 
 
 class BatchCounts(C.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     "dvae_last_error": (C.c_char_p, []),
     "dvae_version": (_I, []),
     "dvae_gemm_f32": (_I, [C.POINTER(GemmDesc), _P]),
+    "dvae_gemm_bf16": (_I, [C.POINTER(GemmDesc), _P]),
     "dvae_gather_sum_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "dvae_scatter_rows_add_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_gru_pointwise_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P]),

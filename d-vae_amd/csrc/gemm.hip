@@ -25,26 +25,9 @@
 // permutation inside a group is consistent.  Global->LDS is register staged
 // (next tile's loads in flight during the current tile's MFMAs), two LDS
 // buffers, one barrier per K step.
-#include "common.h"
-#include "dvae_hip.h"
+#include "gemm_common.h"
 
 namespace dvae {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer offset past num_records: the load returns 0
-
-struct GemmParams {
-    const float* A; const float* B; float* C;
-    const int* a_rows; const int* b_rows; const int* c_rows;
-    const float* bias;
-    int lda, ldb, ldc;
-    int M, N, K;
-    int act;         // 0 none, 1 relu, 2 tanh
-    int accumulate;  // C += result
-    int split_k;     // >1: atomicAdd into C (C must hold the running sum / zeros)
-    int k_per_split; // multiple of 32
-};
 
 constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
@@ -200,18 +183,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
-    // L2), so workgroup ids that are equal mod 8 share an L2.  Give each such group a contiguous
-    // run of tiles (N fastest), so the tiles that re-read one A row block meet in one L2.
     int m0, n0;
-    {
-        const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
-        const int orig = blockIdx.y * nx + blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        m0 = (id / nx) * BM;
-        n0 = (id % nx) * BN;
-    }
+    tile_origin<BM, BN>(m0, n0);
     int kbeg = 0, kend = p.K;
     if (p.split_k > 1) {
         kbeg = blockIdx.z * p.k_per_split;
@@ -285,34 +258,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    // epilogue: D[row][col], col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int col = n0 + (wn * TN + j) * 32 + cl;
-        if (col >= p.N) continue;
-        float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
-                float* dst = p.C + crow * p.ldc + col;
-                float v = acc[i][j][r];
-                if (p.split_k > 1) {
-                    atomicAdd(dst, v);
-                } else {
-                    v += bv;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = tanhf(v);
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
-    }
+    store_acc<TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -330,21 +276,66 @@ static int launch_cfg(const GemmParams& p, int akm, int bkm, hipStream_t s) {
     return DVAE_OK;
 }
 
-int gemm(const dvae_gemm_desc& d, hipStream_t s) {
+// argument checks common to both kernels; kmult = granularity of K for K-contiguous operands
+int gemm_check(const dvae_gemm_desc& d, int kmult) {
     DVAE_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative size");
     if (d.M == 0 || d.N == 0) return DVAE_OK;
     DVAE_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
     DVAE_REQUIRE(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0, "gemm: operands must be 16-byte aligned");
     DVAE_REQUIRE(d.lda % 4 == 0 && d.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
-    if (!d.a_kmajor) DVAE_REQUIRE(d.K % 32 == 0 && d.lda >= d.K, "gemm: K-contiguous A needs K %% 32 == 0 (K=%d lda=%d)", d.K, d.lda);
+    if (!d.a_kmajor) DVAE_REQUIRE(d.K % kmult == 0 && d.lda >= d.K, "gemm: K-contiguous A needs K %% %d == 0 (K=%d lda=%d)", kmult, d.K, d.lda);
     else DVAE_REQUIRE(d.M % 4 == 0 && d.lda >= d.M, "gemm: K-major A needs M %% 4 == 0 (M=%d lda=%d)", d.M, d.lda);
-    if (!d.b_kmajor) DVAE_REQUIRE(d.K % 32 == 0 && d.ldb >= d.K, "gemm: K-contiguous B needs K %% 32 == 0 (K=%d ldb=%d)", d.K, d.ldb);
+    if (!d.b_kmajor) DVAE_REQUIRE(d.K % kmult == 0 && d.ldb >= d.K, "gemm: K-contiguous B needs K %% %d == 0 (K=%d ldb=%d)", kmult, d.K, d.ldb);
     else DVAE_REQUIRE(d.N % 4 == 0 && d.ldb >= d.N, "gemm: K-major B needs N %% 4 == 0 (N=%d ldb=%d)", d.N, d.ldb);
     DVAE_REQUIRE(d.ldc >= d.N, "gemm: ldc < N");
-    // K-major operands are addressed with 32-bit byte offsets (buffer loads)
-    if (d.a_kmajor) DVAE_REQUIRE((double)d.K * d.lda * 4.0 < 4294967000.0, "gemm: K-major A operand exceeds 4 GiB");
-    if (d.b_kmajor && !d.b_rows) DVAE_REQUIRE((double)d.K * d.ldb * 4.0 < 4294967000.0, "gemm: K-major B operand exceeds 4 GiB");
     DVAE_REQUIRE(d.act >= 0 && d.act <= 2, "gemm: unknown activation %d", d.act);
+    return DVAE_OK;
+}
+
+// K-major operands are addressed with 32-bit byte offsets (buffer loads): a contraction whose
+// K-major operand spans more than 4 GiB runs as a sequence of accumulating K chunks.  Returns
+// the chunk length (a multiple of `bk`; >= K when no chunking is needed) or a negative error.
+int gemm_k_chunk(const dvae_gemm_desc& d, int bk) {
+    const double lim = 4294967000.0;
+    double rowb = 0.0;
+    if (d.a_kmajor) rowb = d.lda * 4.0;
+    if (d.b_kmajor && !d.b_rows && d.ldb * 4.0 > rowb) rowb = d.ldb * 4.0;
+    if (rowb == 0.0 || (double)d.K * rowb < lim) return d.K > 0 ? d.K : 1;
+    DVAE_REQUIRE(d.act == 0, "gemm: a chunked contraction cannot apply an activation");
+    const int kc = (int)(lim / rowb) / bk * bk;
+    DVAE_REQUIRE(kc >= bk, "gemm: leading dimension too large for a K-major operand");
+    return kc;
+}
+// next chunk [k0, k0 + kc) of d -> sub; advances k0; false when done
+bool gemm_next_chunk(const dvae_gemm_desc& d, int kc, int& k0, dvae_gemm_desc& sub) {
+    if (k0 >= d.K) return false;
+    sub = d;
+    sub.K = d.K - k0 < kc ? d.K - k0 : kc;
+    sub.A = d.a_kmajor ? d.A + (size_t)k0 * d.lda : d.A + k0;
+    if (d.b_kmajor) {
+        if (d.b_rows) sub.b_rows = d.b_rows + k0;
+        else sub.B = d.B + (size_t)k0 * d.ldb;
+    } else {
+        sub.B = d.B + k0;
+    }
+    if (k0 > 0) { sub.accumulate = 1; sub.bias = nullptr; }
+    k0 += sub.K;
+    return true;
+}
+
+int gemm(const dvae_gemm_desc& d, hipStream_t s) {
+    DVAE_TRY(gemm_check(d, 32));
+    if (d.M == 0 || d.N == 0) return DVAE_OK;
+    {
+        const int kc = gemm_k_chunk(d, BK);
+        if (kc < 0) return kc;
+        if (kc < d.K) {
+            dvae_gemm_desc sub;
+            int k0 = 0;
+            while (gemm_next_chunk(d, kc, k0, sub)) DVAE_TRY(gemm(sub, s));
+            return DVAE_OK;
+        }
+    }
 
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C;

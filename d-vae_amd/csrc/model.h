@@ -23,7 +23,7 @@ enum ParamId {
 static_assert(P_COUNT == DVAE_NUM_PARAMS, "parameter table size");
 
 struct Dims {
-    int n, T, H, nz, bidir, vid, bn, start_type;
+    int n, T, H, nz, bidir, vid, bn, start_type, bf16;
     int Hp, NZp, Tp, HVp, HEp, V;
 };
 
@@ -35,6 +35,7 @@ static inline int make_dims(const dvae_model_desc* m, Dims& d) {
     d.n = m->max_n; d.T = m->nvt; d.H = m->hs; d.nz = m->nz;
     d.bidir = m->bidir != 0; d.bn = m->is_bn != 0; d.vid = (m->vid != 0) && !d.bn;
     d.start_type = m->start_type;
+    d.bf16 = m->mfma_bf16 != 0;
     d.Hp = round_up(d.H, 32);
     d.NZp = round_up(d.nz, 32);
     d.Tp = 32;
@@ -83,6 +84,7 @@ static inline PackedLayout make_layout(const Dims& d) {
 
 // internal kernels shared between translation units
 int gemm(const dvae_gemm_desc& d, hipStream_t s);
+int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                     float* kld_sum, int B, int nz, int NZp, hipStream_t s);
 int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training,

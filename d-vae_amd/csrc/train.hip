@@ -101,13 +101,18 @@ __global__ void sum_scaled_kernel(const float* x, int n, const float* scale, flo
     } while (0)
 
 // ------------------------------------------------------------------ gemm shorthands
+// Matrix-unit input type of the call in progress (dvae_model_desc.mfma_bf16), set by every
+// entry point before it enqueues anything.
+static thread_local int tl_bf16 = 0;
+static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s) { return tl_bf16 ? gemm_bf16(g, s) : gemm(g, s); }
+
 // Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
 static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
                    int ldy, int M, int N, int K, int act, int acc, hipStream_t s) {
     dvae_gemm_desc g = {};
     g.A = X; g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc;
-    return gemm(g, s);
+    return run_gemm(g, s);
 }
 // dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)
 static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
@@ -115,7 +120,7 @@ static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* d
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
     g.M = M; g.N = K; g.K = N; g.accumulate = acc;
-    return gemm(g, s);
+    return run_gemm(g, s);
 }
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
 static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
@@ -123,7 +128,7 @@ static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const in
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
     g.M = N; g.N = K; g.K = M; g.accumulate = 1;
-    return gemm(g, s);
+    return run_gemm(g, s);
 }
 
 // ------------------------------------------------------------------ side stream
@@ -311,6 +316,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_TRY(check_batch(d, c));
+    tl_bf16 = d.bf16;
     DVAE_REQUIRE(blob && pw && ws && mu && logvar, "dvae_encode_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
@@ -394,6 +400,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_TRY(check_batch(d, c));
+    tl_bf16 = d.bf16;
     DVAE_REQUIRE(blob && pw && ws && dmu && dlogvar && pg, "dvae_encode_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
@@ -498,6 +505,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_TRY(check_batch(d, c));
+    tl_bf16 = d.bf16;
     DVAE_REQUIRE(blob && pw && ws && mu && logvar && out3, "dvae_loss_forward: null pointer");
     DVAE_REQUIRE(!training || eps, "dvae_loss_forward: training mode needs the normal draw eps");
     hipStream_t s = (hipStream_t)stream;
@@ -574,6 +582,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_TRY(check_batch(d, c));
+    tl_bf16 = d.bf16;
     DVAE_REQUIRE(blob && pw && ws && mu && logvar && g3 && dmu && dlogvar && pg, "dvae_loss_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);

@@ -140,8 +140,10 @@ class DVAE(nn.Module):
     """DAG variational autoencoder (reference `models.py:536-875`)."""
     _is_bn = False
 
-    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False, vid=True):
+    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False, vid=True,
+                 mfma_dtype="fp32"):
         super(DVAE, self).__init__()
+        self.mfma_dtype = mfma_dtype
         self.max_n = max_n
         self.nvt = nvt
         self.START_TYPE = START_TYPE
@@ -178,9 +180,11 @@ class DVAE(nn.Module):
 
     # ------------------------------------------------------------------ plumbing
     def _finish_init(self):
+        if self.mfma_dtype not in ("fp32", "bf16"):
+            raise ValueError("mfma_dtype must be 'fp32' or 'bf16'")
         self._desc = _lib.ModelDesc(self.max_n, self.nvt, self.hs, self.nz, int(bool(self.bidir)),
                                     int(bool(self.vid) and not self._is_bn), int(self._is_bn),
-                                    int(self.START_TYPE), int(self.END_TYPE))
+                                    int(self.START_TYPE), int(self.END_TYPE), int(self.mfma_dtype == "bf16"))
         if self.max_n > 64 or self.max_n < 2:
             raise ValueError("max_n must be in 2..64")
         if self.nvt > 32:
@@ -261,6 +265,15 @@ class DVAE(nn.Module):
         arrays = graphs_to_arrays(G, self.max_n)
         return DAGBatch(arrays, self.nvt, self.START_TYPE, self._is_bn, self.get_device())
 
+    def set_mfma_dtype(self, mfma_dtype):
+        """'fp32' (default: every contraction exact fp32, the parity mode) or 'bf16' (matrix-unit
+        operands rounded to bf16, fp32 accumulation; weights and activations stay fp32)."""
+        self.mfma_dtype = mfma_dtype
+        keep = self.eps_override
+        self._finish_init()
+        self.eps_override = keep
+        return self
+
     # ------------------------------------------------------------------ reference API
     def get_device(self):
         if self.device is None:
@@ -327,8 +340,8 @@ class DVAE_BN(DVAE):
     """D-VAE for Bayesian networks (reference `models.py:979-1085`)."""
     _is_bn = True
 
-    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False):
-        super(DVAE_BN, self).__init__(max_n, nvt, START_TYPE, END_TYPE, hs, nz, bidirectional)
+    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False, mfma_dtype="fp32"):
+        super(DVAE_BN, self).__init__(max_n, nvt, START_TYPE, END_TYPE, hs, nz, bidirectional, mfma_dtype=mfma_dtype)
         # re-created after the base constructor, in the reference's order (extra RNG draws)
         self.mapper_forward = nn.Sequential(nn.Linear(self.nvt, hs, bias=False))
         self.mapper_backward = nn.Sequential(nn.Linear(self.nvt, hs, bias=False))

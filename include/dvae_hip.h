@@ -15,7 +15,8 @@
  *     message retrievable with dvae_last_error() (thread-local).
  *   - functions taking `void* stream` (a hipStream_t) only enqueue work on that
  *     stream; they never allocate, never synchronise the device.
- *   - all arithmetic is fp32 (MFMA v_mfma_f32_32x32x2_f32 for contractions).
+ *   - all arithmetic is fp32 (MFMA v_mfma_f32_32x32x2_f32 for contractions) unless the
+ *     model descriptor asks for bf16 matrix-unit inputs (mfma_bf16, reported separately).
  *   - feature dimensions are zero-padded to multiples of 32 ("Hp" = padded hs).
  */
 #ifndef DVAE_HIP_H
@@ -57,6 +58,11 @@ typedef struct dvae_gemm_desc {
     int32_t accumulate;
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
+/* The same product with the operands rounded to bf16 (round to nearest even) on
+ * their way into the matrix unit (v_mfma_f32_32x32x16_bf16, fp32 accumulate);
+ * operands and result stay fp32 in memory.  K-contiguous operands need only
+ * K % 4 == 0.  This is the reduced-precision mode of dvae_model_desc.mfma_bf16. */
+int dvae_gemm_bf16(const dvae_gemm_desc* d, void* stream);
 
 /* out[r][0:width] (+)= sum_{k in [off[r], off[r+1])} src[idx[k]][0:width]
  * The gated-sum over predecessors of models.py:661-669 (padding rows of the
@@ -151,6 +157,9 @@ typedef struct dvae_model_desc {
     int32_t max_n, nvt, hs, nz;
     int32_t bidir, vid, is_bn;
     int32_t start_type, end_type;
+    int32_t mfma_bf16; /* 0: every contraction in exact fp32 (the parity mode); 1: contractions take
+                          bf16-rounded operands with fp32 accumulation (dvae_gemm_bf16); weights,
+                          activations, gradients and all pointwise arithmetic stay fp32 */
 } dvae_model_desc;
 
 /* Parameters are passed as an array of DVAE_NUM_PARAMS device pointers in

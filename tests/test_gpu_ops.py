@@ -16,7 +16,8 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None, bias=None, act=0, acc=0):
+def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None, bias=None, act=0, acc=0,
+          bf16=False):
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
     d.a_rows = a_rows.data_ptr() if a_rows is not None else None
@@ -26,7 +27,8 @@ def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None
     d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), Cm.stride(0)
     d.M, d.N, d.K = M, N, K
     d.a_kmajor, d.b_kmajor, d.act, d.accumulate = akm, bkm, act, acc
-    L.check(L.load().dvae_gemm_f32(C.byref(d), _s()), "gemm")
+    fn = L.load().dvae_gemm_bf16 if bf16 else L.load().dvae_gemm_f32
+    L.check(fn(C.byref(d), _s()), "gemm")
     torch.cuda.synchronize()
 
 
@@ -316,3 +318,85 @@ def test_gated_fused_gather_kernels_match_unfused():
                                       _s()))
     torch.cuda.synchronize()
     assert (dgm_f - dgm_ref).abs().max() < 1e-6
+
+
+# ---------------------------------------------------------------- bf16-input MFMA GEMM
+def _ref_bf16(a, b):
+    """exact product of the bf16-rounded operands (what the kernel computes up to fp32 accumulation)"""
+    return (a.bfloat16().double() @ b.bfloat16().double()).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 512), (100, 96, 64), (7, 32, 36), (4000, 2048, 512), (300, 40, 96),
+                                   (129, 130 // 2 * 2, 200)])
+def test_gemm_bf16_nt(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(A, W, out, M, N, K, bf16=True)
+    ref = _ref_bf16(A, W.t())
+    assert (out - ref).abs().max() <= 2e-6 * K ** 0.5 * 16
+
+
+def test_gemm_bf16_layout_identity_check():
+    K = 64
+    A = torch.eye(K, device="cuda")
+    W = (torch.arange(96 * K, device="cuda", dtype=torch.float32) % 251).reshape(96, K)  # exact in bf16
+    out = torch.zeros(K, 96, device="cuda")
+    _gemm(A, W, out, K, 96, K, bf16=True)
+    assert torch.equal(out, W.t().contiguous())
+    # K-major operands: C = A'^T B' with A' = I stored [k][m], asymmetric B' stored [k][n]
+    A2 = torch.eye(128, device="cuda")
+    B2 = (torch.arange(128 * 96, device="cuda", dtype=torch.float32) % 253).reshape(128, 96)
+    out2 = torch.zeros(128, 96, device="cuda")
+    _gemm(A2, B2, out2, 128, 96, 128, akm=1, bkm=1, acc=1, bf16=True)
+    assert torch.equal(out2, B2)
+    # dgrad form: A K-contiguous, B K-major
+    out3 = torch.zeros(128, 96, device="cuda")
+    _gemm(A2, B2, out3, 128, 96, 128, akm=0, bkm=1, bf16=True)
+    assert torch.equal(out3, B2)
+
+
+def test_gemm_bf16_bias_act_accumulate_gather_scatter():
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows_total, M, N, K = 500, 260, 160, 96
+    X = torch.randn(rows_total, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    a_rows = torch.randperm(rows_total, device="cuda", generator=g)[:M].int()
+    c_rows = torch.randperm(400, device="cuda", generator=g)[:M].int()
+    for act in (0, 1, 2):
+        out = torch.ones(400, N, device="cuda")
+        _gemm(X, W, out, M, N, K, a_rows=a_rows, c_rows=c_rows, bias=bias, act=act, acc=1, bf16=True)
+        y = _ref_bf16(X[a_rows.long()], W.t()) + bias
+        y = [y, torch.relu(y), torch.tanh(y)][act]
+        ref = torch.ones(400, N, device="cuda")
+        ref[c_rows.long()] += y
+        assert (out - ref).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1536, 512), (77, 2048 // 4, 100), (1024, 512, 1024)])
+def test_gemm_bf16_dgrad_kmajor_b(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(6)
+    dY = torch.randn(M, N, device="cuda", generator=g)   # dX[M,K] = dY[M,N] W[N,K]
+    W = torch.randn(N, K, device="cuda", generator=g)
+    out = torch.zeros(M, K, device="cuda")
+    _gemm(dY, W, out, M, K, N, akm=0, bkm=1, acc=1, bf16=True)
+    ref = _ref_bf16(dY, W)
+    assert (out - ref).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("rows,N,K", [(8192, 1536, 512), (333, 64, 32), (5000, 32, 1536), (70, 128, 512), (9251, 2048, 512)])
+def test_gemm_bf16_wgrad_splitk(rows, N, K):
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    dY = torch.randn(rows, N, device="cuda", generator=g)
+    X = torch.randn(rows + 50, K, device="cuda", generator=g)
+    b_rows = torch.randperm(rows + 50, device="cuda", generator=g)[:rows].int()
+    out = torch.zeros(N, K, device="cuda")
+    _gemm(dY, X, out, N, K, rows, akm=1, bkm=1, b_rows=b_rows, acc=1, bf16=True)
+    ref = _ref_bf16(dY.t(), X[b_rows.long()])
+    assert (out - ref).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
+    out2 = torch.zeros(N, K, device="cuda")
+    _gemm(dY, X, out2, N, K, rows, akm=1, bkm=1, acc=1, bf16=True)
+    ref2 = _ref_bf16(dY.t(), X[:rows])
+    assert (out2 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4

@@ -172,3 +172,63 @@ def test_full_batch_properties_cfg2():
     assert abs(l3.item() - r64[0].item()) <= TOL * abs(r64[0].item())
     assert rel_err(mu3, r64[3]) < TOL
     assert_grads_match(model, r32, r64, TOL)
+
+
+def test_max_size_graphs_n64_match_oracle():
+    """max_n = 64 (the predecessor masks use all 64 bits), ragged sizes, bidirectional."""
+    rng = np.random.default_rng(64)
+    n, T, hs, nz, B = 64, 18, 32, 8, 6
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=1)
+    model = make_model("DVAE", ctor, 5)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.08, True)
+    n_g[0] = n  # at least one full-size graph
+    types[0, 1:n - 1] = rng.integers(2, T, size=n - 2)
+    types[0, n - 1] = 1
+    types[0, n_g[0]:] = 0
+    for v in range(1, n):
+        adj[0, v - 1, v] = 1
+    adj[0, 0, n - 1] = 1  # bit 0 and bit 62 of the last vertex's mask
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    r32, r64 = oracle_truth("DVAE", ctor, sd, types, adj, n_g, eps)
+    model.cuda()
+    loss, res, kld, mu, logvar = _run(model, dvae_amd.GraphArrays.from_dense(types, adj, n_g), eps)
+    assert abs(loss.item() - r64[0].item()) <= TOL * abs(r64[0].item())
+    assert rel_err(mu, r64[3]) < TOL and rel_err(logvar, r64[4]) < TOL
+    assert_grads_match(model, r32, r64, TOL)
+
+
+# bf16 matrix-unit inputs (mfma_dtype="bf16"): reported separately from the fp32 parity mode.
+# Operands are rounded to 8 mantissa bits before every contraction (relative 2^-9 per element),
+# accumulation and all pointwise arithmetic stay fp32.  Stated tolerance: loss 5e-3 relative,
+# mu / logvar 2e-2 (norm-wise), each gradient tensor 6e-2 (norm-wise) against the fp64 oracle.
+BF16_TOL_LOSS, BF16_TOL_LATENT, BF16_TOL_GRAD = 5e-3, 2e-2, 6e-2
+
+
+@pytest.mark.parametrize("cls,bidir,var", [("DVAE", True, True), ("DVAE_BN", False, False)])
+def test_bf16_mode_close_to_oracle(cls, bidir, var):
+    rng = np.random.default_rng(12)
+    n, T, hs, nz, B = 9, 7, 72, 10, 48
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=int(bidir))
+    model = make_model(cls, ctor, 3)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.35, var)
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    r32, r64 = oracle_truth(cls, ctor, sd, types, adj, n_g, eps)
+    model.set_mfma_dtype("bf16").cuda()
+    loss, res, kld, mu, logvar = _run(model, dvae_amd.GraphArrays.from_dense(types, adj, n_g), eps)
+    assert abs(loss.item() - r64[0].item()) <= BF16_TOL_LOSS * abs(r64[0].item())
+    assert rel_err(mu, r64[3]) < BF16_TOL_LATENT and rel_err(logvar, r64[4]) < BF16_TOL_LATENT
+    worst = 0.0
+    for k, p in model.named_parameters():
+        g64 = r64[5][k]
+        if g64 is None:
+            assert p.grad is None, k
+            continue
+        e = rel_err(p.grad, g64)
+        worst = max(worst, e)
+        assert e < BF16_TOL_GRAD, "%s: %.3e" % (k, e)
+    # and it is a different computation from the fp32 mode (the flag is not silently ignored)
+    assert rel_err(mu, r64[3]) > 1e-5
+    print("bf16 mode: loss rel %.2e, mu rel %.2e, worst grad rel %.2e"
+          % (abs(loss.item() - r64[0].item()) / abs(r64[0].item()), rel_err(mu, r64[3]), worst))

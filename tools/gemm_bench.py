@@ -27,7 +27,12 @@ SHAPES = [
     ("wgrad Whh       ", 1536, 512, 8192, 1, 1, 1),
     ("wgrad Wgm       ", 1024, 512, 8192, 1, 1, 1),
     ("square 4096     ", 4096, 4096, 4096, 0, 0, 0),
+    ("square 8192     ", 8192, 8192, 8192, 0, 0, 0),
 ]
+
+
+BF16 = os.environ.get("DVAE_GEMM_BF16") == "1"
+PEAK = 2500.0 if BF16 else 157.3
 
 
 def run(label, M, N, K, akm, bkm, acc, iters=20):
@@ -40,19 +45,20 @@ def run(label, M, N, K, akm, bkm, acc, iters=20):
     d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), N
     d.M, d.N, d.K = M, N, K
     d.a_kmajor, d.b_kmajor, d.accumulate = akm, bkm, acc
+    fn = lib.dvae_gemm_bf16 if BF16 else lib.dvae_gemm_f32
     st = torch.cuda.current_stream()
     sp = C.c_void_p(st.cuda_stream)
     for _ in range(3):
-        L.check(lib.dvae_gemm_f32(C.byref(d), sp))
+        L.check(fn(C.byref(d), sp))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(iters):
-        lib.dvae_gemm_f32(C.byref(d), sp)
+        fn(C.byref(d), sp)
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * M * N * K / ms / 1e9
-    print("%s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s  (%4.1f%% of 157.3)" % (label, M, N, K, ms * 1e3, tf, tf / 1.573))
+    print("%s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s  (%4.1f%% of %.1f)" % (label, M, N, K, ms * 1e3, tf, tf / PEAK * 100, PEAK))
 
 
 if __name__ == "__main__":
