@@ -58,8 +58,9 @@ SIGNATURES = {
     "dvae_gated_fwd_gather": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_gated_bwd_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dvae_segment_colsum_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
-    "dvae_pair_bce_fwd": (_I, [_P] * 12 + [_I, _I, _P]),
-    "dvae_pair_bce_bwd_grouped": (_I, [_P] * 14 + [_I, _I, _I, _P]),
+    "dvae_pair_mask_words": (C.c_int64, [_I, _I]),
+    "dvae_pair_bce_fwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),
+    "dvae_pair_bce_bwd_grouped": (_I, [_P] * 8 + [_I, _I, _P]),
     "dvae_vertex_ce": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dvae_packed_floats": (C.c_int64, [_MD]),
     "dvae_pack_weights": (_I, [_MD, C.POINTER(_P), _P, _P]),

@@ -13,124 +13,164 @@ namespace dvae {
 __device__ __forceinline__ float4 ld4c(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---------------------------------------------------------------------------
-// forward: one wave per pair (grid-stride)
+// Edge predictor tail + BCE.  A wave owns a pair; lane l holds the 4 hidden units
+// c = 4 l + 256 i + {0..3} of iteration i (coalesced float4 rows).  NIT = number of
+// iterations (HEp <= 256 NIT), compile-time so the per-pair values stay in registers.
+//
+// forward, per pair: s = b2 + sum_j w2[j] relu(pre[j]),  pre = EA[a] + EB[h] (+ EC[c]) + b1
+//   -> loss term, dl = d loss / d s, the ReLU MASK of the pair (1 bit per hidden unit:
+//   word (p, i / 8, lane), bit 4 (i % 8) + component) and, accumulated over the pairs of the
+//   workgroup, the w2 gradient partial  sum_p dl[p] relu(pre_p[j])  (unscaled by the upstream
+//   gradient).  With the mask stored, the backward passes never re-read EA / EB.
+template <int NIT>
 __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__ ea, const float* __restrict__ eb,
                                                        const float* __restrict__ ec, const int* __restrict__ pair_a,
                                                        const int* __restrict__ pair_h, const int* __restrict__ pair_c,
                                                        const uint8_t* __restrict__ pair_t, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ dl, float* __restrict__ loss_sum,
+                                                       uint32_t* __restrict__ mask, float* __restrict__ dw2_partial,
                                                        int n_pairs, int HEp) {
-    __shared__ float red[4];
+    constexpr int NW = (NIT + 7) / 8;
+    extern __shared__ float sh[];  // [HEp] workgroup sum of the w2-gradient partials (+ 4 floats)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_total = gridDim.x * 4;
+    if (dw2_partial) {
+        for (int c = threadIdx.x; c < HEp; c += 256) sh[c] = 0.f;
+    }
     float local = 0.f;
     const float bias2 = b2[0];
+    float aw[NIT * 4];
+#pragma unroll
+    for (int i = 0; i < NIT * 4; ++i) aw[i] = 0.f;
     for (int p = blockIdx.x * 4 + wave; p < n_pairs; p += waves_total) {
         const float* ra = ea + (long)pair_a[p] * HEp;
         const float* rb = eb + (long)pair_h[p] * HEp;
         const float* rc = ec ? ec + (long)pair_c[p] * HEp : nullptr;
+        float rv[NIT * 4];
+        uint32_t mw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mw[w] = 0u;
         float s = 0.f;
-        for (int c = lane * 4; c < HEp; c += 256) {
-            float4 a = ld4c(ra + c), b = ld4c(rb + c), bb = ld4c(b1 + c), w = ld4c(w2 + c);
-            float4 pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
-            if (rc) {
-                float4 cc = ld4c(rc + c);
-                pre.x += cc.x; pre.y += cc.y; pre.z += cc.z; pre.w += cc.w;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = lane * 4 + 256 * i;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < HEp) {
+                float4 a = ld4c(ra + c), b = ld4c(rb + c), bb = ld4c(b1 + c), w = ld4c(w2 + c);
+                float4 pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
+                if (rc) {
+                    float4 cc = ld4c(rc + c);
+                    pre.x += cc.x; pre.y += cc.y; pre.z += cc.z; pre.w += cc.w;
+                }
+                r = make_float4(fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f));
+                uint32_t bits = (pre.x > 0.f ? 1u : 0u) | (pre.y > 0.f ? 2u : 0u) | (pre.z > 0.f ? 4u : 0u) |
+                                (pre.w > 0.f ? 8u : 0u);
+                mw[i / 8] |= bits << (4 * (i % 8));
+                s += w.x * r.x + w.y * r.y + w.z * r.z + w.w * r.w;
             }
-            s += w.x * fmaxf(pre.x, 0.f) + w.y * fmaxf(pre.y, 0.f) + w.z * fmaxf(pre.z, 0.f) + w.w * fmaxf(pre.w, 0.f);
+            rv[4 * i + 0] = r.x; rv[4 * i + 1] = r.y; rv[4 * i + 2] = r.z; rv[4 * i + 3] = r.w;
         }
         s = wave_sum(s) + bias2;
+        // torch.sigmoid then F.binary_cross_entropy on the probability (models.py:745, :855)
+        float prob = 1.f / (1.f + expf(-s));
+        float t = (float)pair_t[p];
+        float lp = fmaxf(logf(prob), -100.f);
+        float lq = fmaxf(logf(1.f - prob), -100.f);
+        // BCE backward: (p - t) / max(p (1-p), 1e-12), then sigmoid backward: * p (1-p)
+        float pq = prob * (1.f - prob);
+        float g = (prob - t) / fmaxf(pq, 1e-12f) * pq;
         if (lane == 0) {
-            // torch.sigmoid then F.binary_cross_entropy on the probability (models.py:745, :855)
-            float prob = 1.f / (1.f + expf(-s));
-            float t = (float)pair_t[p];
-            float lp = fmaxf(logf(prob), -100.f);
-            float lq = fmaxf(logf(1.f - prob), -100.f);
             local += -(t * lp + (1.f - t) * lq);
-            // BCE backward: (p - t) / max(p (1-p), 1e-12), then sigmoid backward: * p (1-p)
-            float pq = prob * (1.f - prob);
-            dl[p] = (prob - t) / fmaxf(pq, 1e-12f) * pq;
+            dl[p] = g;
+        }
+        if (mask) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mask[((long)p * NW + w) * 64 + lane] = mw[w];
+        }
+        if (dw2_partial) {
+#pragma unroll
+            for (int i = 0; i < NIT * 4; ++i) aw[i] += g * rv[i];
         }
     }
+    float* red = sh + HEp;
     if (lane == 0) red[wave] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
         float v = red[0] + red[1] + red[2] + red[3];
         if (v != 0.f) atomicAdd(loss_sum, v);
     }
+    if (dw2_partial) {  // uniform
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < HEp) {
+                atomicAdd(&sh[c + 0], aw[4 * i + 0]);
+                atomicAdd(&sh[c + 1], aw[4 * i + 1]);
+                atomicAdd(&sh[c + 2], aw[4 * i + 2]);
+                atomicAdd(&sh[c + 3], aw[4 * i + 3]);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < HEp; c += 256) dw2_partial[(long)blockIdx.x * HEp + c] = sh[c];
+    }
 }
 
 // ---------------------------------------------------------------------------
-// grouped backward: one wave per chunk of pairs that share the same `mine` row.
-//   chunk q covers grp_pairs[chunk_off[q] .. chunk_off[q+1]) (grp_pairs == NULL:
-//   the pair ids are the positions themselves); chunk_row[q] = destination row,
-//   bit 31 set when several chunks share the row (-> atomicAdd into zeroed dmine).
-__global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__ mine,
-                                                       const int* __restrict__ chunk_off,
+// grouped backward: one wave per chunk of pairs that share one row of an edge-predictor table.
+//   chunk q covers grp_pairs[chunk_off[q] .. chunk_off[q+1]) (grp_pairs == NULL: the pair ids
+//   are the positions themselves); chunk_row[q] = destination row, bit 31 set when several
+//   chunks share the row (-> atomicAdd into the zeroed table).
+//   d table[row][j] = scale * w2[j] * sum_p dl[p] mask_p[j]
+__device__ __forceinline__ float sel(uint32_t w, int bit, float g) { return (w >> bit) & 1u ? g : 0.f; }
+
+template <int NIT>
+__global__ __launch_bounds__(256) void pair_bwd_kernel(const int* __restrict__ chunk_off,
                                                        const int* __restrict__ chunk_row,
-                                                       const int* __restrict__ grp_pairs,
-                                                       const float* __restrict__ oth1, const int* __restrict__ oth1_idx,
-                                                       const float* __restrict__ oth2, const int* __restrict__ oth2_idx,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ dl, const float* __restrict__ scale,
-                                                       float* __restrict__ dmine, float* __restrict__ dw2_partial,
+                                                       const int* __restrict__ grp_pairs, const float* __restrict__ dl,
+                                                       const uint32_t* __restrict__ mask, const float* __restrict__ w2,
+                                                       const float* __restrict__ scale, float* __restrict__ dtab,
                                                        int n_chunks, int HEp) {
-    __shared__ float4 red[4][64];
+    constexpr int NW = (NIT + 7) / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_total = gridDim.x * 4;
     const float sc = scale ? scale[0] : 1.f;
-    for (int c0 = 0; c0 < HEp; c0 += 256) {  // uniform trip count: the loop body holds barriers
-        const bool act = (c0 + lane * 4) < HEp;
-        const int c = act ? c0 + lane * 4 : 0;
-        float4 bb = ld4c(b1 + c), w = ld4c(w2 + c);
-        float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = blockIdx.x * 4 + wave; q < n_chunks; q += waves_total) {
-            int cr = chunk_row[q];
-            int row = cr & 0x7fffffff;
-            float4 m = ld4c(mine + (long)row * HEp + c);
-            m.x += bb.x; m.y += bb.y; m.z += bb.z; m.w += bb.w;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int k1 = chunk_off[q + 1];
-            for (int k = chunk_off[q]; k < k1; ++k) {
-                int p = grp_pairs ? grp_pairs[k] : k;
-                float g = dl[p] * sc;
-                float4 o = ld4c(oth1 + (long)oth1_idx[p] * HEp + c);
-                float4 pre = make_float4(m.x + o.x, m.y + o.y, m.z + o.z, m.w + o.w);
-                if (oth2) {
-                    float4 o2 = ld4c(oth2 + (long)oth2_idx[p] * HEp + c);
-                    pre.x += o2.x; pre.y += o2.y; pre.z += o2.z; pre.w += o2.w;
-                }
-                acc.x += pre.x > 0.f ? g * w.x : 0.f;
-                acc.y += pre.y > 0.f ? g * w.y : 0.f;
-                acc.z += pre.z > 0.f ? g * w.z : 0.f;
-                acc.w += pre.w > 0.f ? g * w.w : 0.f;
-                aw.x += g * fmaxf(pre.x, 0.f);
-                aw.y += g * fmaxf(pre.y, 0.f);
-                aw.z += g * fmaxf(pre.z, 0.f);
-                aw.w += g * fmaxf(pre.w, 0.f);
-            }
-            if (act) {
-                float* d = dmine + (long)row * HEp + c;
-                if (cr < 0) {
-                    atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
-                } else {
-                    *reinterpret_cast<float4*>(d) = acc;
-                }
-            }
+    for (int q = blockIdx.x * 4 + wave; q < n_chunks; q += waves_total) {
+        const int cr = chunk_row[q];
+        const int row = cr & 0x7fffffff;
+        float acc[NIT * 4];
+#pragma unroll
+        for (int i = 0; i < NIT * 4; ++i) acc[i] = 0.f;
+        const int k1 = chunk_off[q + 1];
+        for (int k = chunk_off[q]; k < k1; ++k) {
+            const int p = grp_pairs ? grp_pairs[k] : k;
+            const float g = dl[p] * sc;
+            uint32_t mw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mw[w] = mask[((long)p * NW + w) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < NIT * 4; ++i) acc[i] += sel(mw[i / 32], i % 32, g);
         }
-        if (dw2_partial) {  // uniform branch
-            red[wave][lane] = aw;
-            __syncthreads();
-            if (wave == 0 && act) {
-                float4 a = red[0][lane], b = red[1][lane], cc = red[2][lane], dd = red[3][lane];
-                float4 s = make_float4(a.x + b.x + cc.x + dd.x, a.y + b.y + cc.y + dd.y, a.z + b.z + cc.z + dd.z,
-                                       a.w + b.w + cc.w + dd.w);
-                *reinterpret_cast<float4*>(dw2_partial + (long)blockIdx.x * HEp + c) = s;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < HEp) {
+                float4 w = ld4c(w2 + c);
+                float4 v = make_float4(acc[4 * i] * w.x, acc[4 * i + 1] * w.y, acc[4 * i + 2] * w.z, acc[4 * i + 3] * w.w);
+                float* d = dtab + (long)row * HEp + c;
+                if (cr < 0) {
+                    atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+                } else {
+                    *reinterpret_cast<float4*>(d) = v;
+                }
             }
-            __syncthreads();
         }
     }
+}
+
+__global__ void scale_inplace_kernel(float* x, const float* s, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -221,33 +261,68 @@ __global__ void reparam_kld_bwd_kernel(const float* __restrict__ mu, const float
 
 using namespace dvae;
 
+static int pair_nit(int HEp) {
+    int it = cdiv(HEp, 256);
+    return it <= 1 ? 1 : it <= 2 ? 2 : it <= 4 ? 4 : it <= 8 ? 8 : it <= 16 ? 16 : -1;
+}
+
+extern "C" int64_t dvae_pair_mask_words(int32_t n_pairs, int32_t HEp) {
+    int nit = pair_nit(HEp);
+    if (nit < 0 || n_pairs < 0) return -1;
+    return (int64_t)n_pairs * ((nit + 7) / 8) * 64;
+}
+
 extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a,
                                  const int32_t* pair_h, const int32_t* pair_c, const uint8_t* pair_t, const float* b1,
-                                 const float* w2, const float* b2, float* dl, float* loss_sum, int32_t n_pairs,
-                                 int32_t HEp, void* stream) {
-    if (n_pairs == 0) return DVAE_OK;
+                                 const float* w2, const float* b2, float* dl, float* loss_sum, uint32_t* mask,
+                                 float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp, void* stream) {
     DVAE_REQUIRE(ea && eb && pair_a && pair_h && pair_t && b1 && w2 && b2 && dl && loss_sum, "pair_bce_fwd: null pointer");
     DVAE_REQUIRE((ec == nullptr) == (pair_c == nullptr), "pair_bce_fwd: ec and pair_c go together");
-    DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0, "pair_bce_fwd: HEp must be a multiple of 4");
-    int blocks = cdiv(n_pairs, 4);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pair_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ea, eb, ec, pair_a, pair_h,
-                       pair_c, pair_t, b1, w2, b2, dl, loss_sum, n_pairs, HEp);
+    DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0 && n_blocks > 0, "pair_bce_fwd: HEp must be a multiple of 4, n_blocks > 0");
+    const int nit = pair_nit(HEp);
+    DVAE_REQUIRE(nit > 0, "pair_bce_fwd: HEp %d exceeds 4096", HEp);
+    if (n_pairs == 0 && !dw2_partial) return DVAE_OK;
+    const size_t shm = ((size_t)HEp + 4) * sizeof(float);
+    dim3 grid(n_blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define DVAE_PAIR_FWD(N)                                                                                              \
+    hipLaunchKernelGGL((pair_fwd_kernel<N>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, \
+                       b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp)
+    switch (nit) {
+        case 1: DVAE_PAIR_FWD(1); break;
+        case 2: DVAE_PAIR_FWD(2); break;
+        case 4: DVAE_PAIR_FWD(4); break;
+        case 8: DVAE_PAIR_FWD(8); break;
+        default: DVAE_PAIR_FWD(16); break;
+    }
+#undef DVAE_PAIR_FWD
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
 
-extern "C" int dvae_pair_bce_bwd_grouped(const float* mine, const int32_t* chunk_off, const int32_t* chunk_row,
-                                         const int32_t* grp_pairs, const float* oth1, const int32_t* oth1_idx,
-                                         const float* oth2, const int32_t* oth2_idx, const float* b1, const float* w2,
-                                         const float* dl, const float* scale, float* dmine, float* dw2_partial,
-                                         int32_t n_chunks, int32_t HEp, int32_t n_blocks, void* stream) {
+extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,
+                                         const float* dl, const uint32_t* mask, const float* w2, const float* scale,
+                                         float* dtab, int32_t n_chunks, int32_t HEp, void* stream) {
     if (n_chunks == 0) return DVAE_OK;
-    DVAE_REQUIRE(mine && chunk_off && chunk_row && oth1 && oth1_idx && b1 && w2 && dl && dmine, "pair_bce_bwd: null pointer");
-    DVAE_REQUIRE((oth2 == nullptr) == (oth2_idx == nullptr), "pair_bce_bwd: oth2 and oth2_idx go together");
-    DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0 && n_blocks > 0, "pair_bce_bwd: bad size");
-    hipLaunchKernelGGL(pair_bwd_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, mine, chunk_off, chunk_row,
-                       grp_pairs, oth1, oth1_idx, oth2, oth2_idx, b1, w2, dl, scale, dmine, dw2_partial, n_chunks, HEp);
+    DVAE_REQUIRE(chunk_off && chunk_row && dl && mask && w2 && dtab, "pair_bce_bwd: null pointer");
+    DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0, "pair_bce_bwd: bad size");
+    const int nit = pair_nit(HEp);
+    DVAE_REQUIRE(nit > 0, "pair_bce_bwd: HEp %d exceeds 4096", HEp);
+    int blocks = cdiv(n_chunks, 4);
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid(blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define DVAE_PAIR_BWD(N)                                                                                            \
+    hipLaunchKernelGGL((pair_bwd_kernel<N>), grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, \
+                       dtab, n_chunks, HEp)
+    switch (nit) {
+        case 1: DVAE_PAIR_BWD(1); break;
+        case 2: DVAE_PAIR_BWD(2); break;
+        case 4: DVAE_PAIR_BWD(4); break;
+        case 8: DVAE_PAIR_BWD(8); break;
+        default: DVAE_PAIR_BWD(16); break;
+    }
+#undef DVAE_PAIR_BWD
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -264,6 +339,12 @@ extern "C" int dvae_vertex_ce(const float* logits, int32_t ld, const int32_t* ce
 }
 
 namespace dvae {
+int scale_inplace(float* x, const float* s, int n, hipStream_t st) {
+    if (n <= 0) return DVAE_OK;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, s, n);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                     float* kld_sum, int B, int nz, int NZp, hipStream_t s) {
     hipLaunchKernelGGL(reparam_kld_fwd_kernel, dim3(cdiv((long)B * NZp, 256)), dim3(256), 0, s, mu, logvar, eps,

@@ -225,6 +225,7 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
 struct DecWs {
     float *z, *agg, *gates, *ghn, *st, *gm, *msg;
     float *ea, *eb, *ec, *dl, *vs, *v1, *logits, *dlogits, *sums, *xoh, *cnt;
+    uint32_t* mask;  // ReLU masks of the edge predictor, one bit per (pair, hidden unit)
     // backward
     float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dgm, *dh0c, *dz, *gs;
     int dw2_blocks;
@@ -245,6 +246,7 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.eb = b.take((size_t)(c.NB + 1) * HEp);
     w.ec = d.bn ? b.take((size_t)c.B * HEp) : nullptr;
     w.dl = b.take(c.NP);
+    w.mask = reinterpret_cast<uint32_t*>(b.take((size_t)dvae_pair_mask_words(c.NP, d.HEp)));
     w.vs = b.take((size_t)c.R * Hp);
     w.v1 = b.take((size_t)c.R * d.HVp);
     w.logits = b.take((size_t)c.R * d.Tp);
@@ -564,7 +566,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_HIP(hipMemsetAsync(w.eb + (size_t)c->NB * HEp, 0, sizeof(float) * HEp, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
     DVAE_TRY(dvae_pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t,
-                               pw + L.be1, pw + L.we2, pw + L.be2, w.dl, w.sums + 0, c->NP, HEp, s));
+                               pw + L.be1, pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, w.dw2_blocks,
+                               c->NP, HEp, s));
     // vertex-type predictor
     DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
     DVAE_TRY(lin_fwd(w.vs, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1, d.HVp, c->R, d.HVp, Hp, 1, 0, s));
@@ -599,16 +602,15 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     // ---- edge predictor ------------------------------------------------------------
     DVAE_HIP(hipMemsetAsync(w.dea, 0, sizeof(float) * (size_t)(c->NA + 1) * HEp, s));
     DVAE_HIP(hipMemsetAsync(w.deb, 0, sizeof(float) * (size_t)(c->NB + 1) * HEp, s));
-    const int* pc = d.bn ? bv.pair_c : nullptr;
-    DVAE_TRY(dvae_pair_bce_bwd_grouped(w.ea, bv.ca_off, bv.ca_row, bv.ca_pairs, w.eb, bv.pair_h, w.ec, pc, pw + L.be1,
-                                       pw + L.we2, w.dl, g_res, w.dea, w.dw2p, c->CA, HEp, w.dw2_blocks, s));
-    DVAE_TRY(dvae_pair_bce_bwd_grouped(w.eb, bv.ch_off, bv.ch_row, bv.ch_pairs, w.ea, bv.pair_a, w.ec, pc, pw + L.be1,
-                                       pw + L.we2, w.dl, g_res, w.deb, nullptr, c->CH, HEp, w.dw2_blocks, s));
+    // the forward left the ReLU masks: each pass is one sweep over (dl, mask) and writes its table
+    DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.ca_off, bv.ca_row, bv.ca_pairs, w.dl, w.mask, pw + L.we2, g_res, w.dea,
+                                       c->CA, HEp, s));
+    DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.ch_off, bv.ch_row, bv.ch_pairs, w.dl, w.mask, pw + L.we2, g_res, w.deb,
+                                       c->CH, HEp, s));
     if (d.bn) {
         DVAE_HIP(hipMemsetAsync(w.dec, 0, sizeof(float) * (size_t)B * HEp, s));
-        DVAE_TRY(dvae_pair_bce_bwd_grouped(w.ec, bv.cc_off, bv.cc_row, nullptr, w.ea, bv.pair_a, w.eb, bv.pair_h,
-                                           pw + L.be1, pw + L.we2, w.dl, g_res, w.dec, nullptr, c->CC, HEp,
-                                           w.dw2_blocks, s));
+        DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.cc_off, bv.cc_row, nullptr, w.dl, w.mask, pw + L.we2, g_res, w.dec,
+                                           c->CC, HEp, s));
     }
     // The predictors' weight gradients depend only on what is already computed; they run on the
     // side stream while the main stream continues into the (latency-bound) state chain.
@@ -623,6 +625,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     {
         hipStream_t s2 = side->stream;
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s2));
+        DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
         DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2));

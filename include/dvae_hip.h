@@ -122,25 +122,28 @@ int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t 
  *   s = b2 + sum_j w2[j] relu(EA[a_p][j] + EB[h_p][j] (+ EC[c_p][j]) + b1[j])
  *   prob = sigmoid(s);  loss_p = -(t log prob + (1-t) log(1-prob)), logs clamped at -100
  * Writes dl[p] = d loss_p / d s (PyTorch BCE-on-probabilities backward) and adds
- * sum_p loss_p into *loss_sum.  ec/pair_c nullable (DVAE). */
+ * sum_p loss_p into *loss_sum.  ec/pair_c nullable (DVAE).
+ * For the backward passes it also leaves (both nullable):
+ *   mask         the ReLU mask of every pair, dvae_pair_mask_words(n_pairs, HEp) uint32 words
+ *                (1 bit per hidden unit; layout private to the two kernels)
+ *   dw2_partial  [n_blocks][HEp]: per-workgroup partial sums of dl[p] relu(pre_p[j]); their
+ *                column sum times the upstream gradient is the gradient of w2.
+ * The launch uses exactly n_blocks workgroups. */
+int64_t dvae_pair_mask_words(int32_t n_pairs, int32_t HEp);
 int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a,
                       const int32_t* pair_h, const int32_t* pair_c, const uint8_t* pair_t, const float* b1,
-                      const float* w2, const float* b2, float* dl, float* loss_sum, int32_t n_pairs, int32_t HEp,
-                      void* stream);
-/* Grouped backward pass.  The pairs that share one row of `mine` form a group;
- * groups are cut into chunks (one wavefront each): chunk q covers
- * grp_pairs[chunk_off[q] .. chunk_off[q+1]) (grp_pairs NULL: the positions are
- * the pair ids), chunk_row[q] = the row, with bit 31 set when the row has more
- * than one chunk (those chunks atomicAdd into the pre-zeroed dmine).
- *   dmine[row][j] = scale * sum_p dl[p] w2[j] [pre_p[j] > 0],
- *   pre_p = mine[row] + oth1[oth1_idx[p]] (+ oth2[oth2_idx[p]]) + b1.
- * dw2_partial (nullable) [n_blocks][HEp] receives per-workgroup partial sums of
- * scale * dl[p] relu(pre_p[j]). */
-int dvae_pair_bce_bwd_grouped(const float* mine, const int32_t* chunk_off, const int32_t* chunk_row,
-                              const int32_t* grp_pairs, const float* oth1, const int32_t* oth1_idx,
-                              const float* oth2, const int32_t* oth2_idx, const float* b1, const float* w2,
-                              const float* dl, const float* scale, float* dmine, float* dw2_partial,
-                              int32_t n_chunks, int32_t HEp, int32_t n_blocks, void* stream);
+                      const float* w2, const float* b2, float* dl, float* loss_sum, uint32_t* mask,
+                      float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp, void* stream);
+/* Grouped backward pass onto one of the edge-predictor tables.  The pairs that
+ * share one row of the table form a group; groups are cut into chunks (one
+ * wavefront each): chunk q covers grp_pairs[chunk_off[q] .. chunk_off[q+1])
+ * (grp_pairs NULL: the positions are the pair ids), chunk_row[q] = the row, with
+ * bit 31 set when the row has more than one chunk (those chunks atomicAdd into
+ * the pre-zeroed table).
+ *   dtab[row][j] = scale * w2[j] * sum_p dl[p] [pre_p[j] > 0]   (mask from the forward) */
+int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,
+                              const float* dl, const uint32_t* mask, const float* w2, const float* scale,
+                              float* dtab, int32_t n_chunks, int32_t HEp, void* stream);
 
 /* Vertex-type CE (models.py:823-826): per row of logits [R][ld] with T valid
  * columns and a CSR list of targets, adds -sum log_softmax[target] into

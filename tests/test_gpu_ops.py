@@ -203,11 +203,15 @@ def test_pair_kernels_match_torch():
     dl = torch.zeros(NP, device="cuda")
     lsum = torch.zeros(1, device="cuda")
     pa_i, ph_i, tgt_u = pa.int(), ph.int(), tgt.to(torch.uint8)
+    nblk = 8
+    mask = torch.zeros(int(lib.dvae_pair_mask_words(NP, HEp)), dtype=torch.int32, device="cuda")
+    dw2p = torch.full((nblk, HEp), float("nan"), device="cuda")
     L.check(lib.dvae_pair_bce_fwd(ea.data_ptr(), eb.data_ptr(), None, pa_i.data_ptr(), ph_i.data_ptr(), None,
                                   tgt_u.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                  dl.data_ptr(), lsum.data_ptr(), NP, HEp, _s()))
+                                  dl.data_ptr(), lsum.data_ptr(), mask.data_ptr(), dw2p.data_ptr(), nblk, NP, HEp, _s()))
     assert abs(lsum.item() - ref.item()) < 1e-4 * ref.item()
     assert abs(dl.sum().item() - b2.grad.item()) < 1e-4
+    assert (dw2p.sum(0) - w2.grad).abs().max() < 1e-3
     # grouped backward by the EA row, chunks of 4 pairs
     def chunks(key, nrows, ch):
         order = torch.argsort(key.cpu(), stable=True)
@@ -222,18 +226,55 @@ def test_pair_kernels_match_torch():
         off.append(NP)
         row = np.array(row, np.uint32).view(np.int32)
         return (torch.tensor(off, dtype=torch.int32).cuda(), torch.from_numpy(row).cuda(), order.int().cuda())
-    for mine, key, nrows, oth, oidx, gref in ((ea, pa, NA + 1, eb, ph_i, ea.grad), (eb, ph, NB + 1, ea, pa_i, eb.grad)):
+    for mine, key, nrows, gref in ((ea, pa, NA + 1, ea.grad), (eb, ph, NB + 1, eb.grad)):
         off, row, pairs = chunks(key, nrows, 4)
         dm = torch.zeros_like(mine)
-        nblk = 8
-        dw2p = torch.zeros(nblk, HEp, device="cuda")
-        L.check(lib.dvae_pair_bce_bwd_grouped(mine.data_ptr(), off.data_ptr(), row.data_ptr(), pairs.data_ptr(),
-                                              oth.data_ptr(), oidx.data_ptr(), None, None, b1.data_ptr(),
-                                              w2.data_ptr(), dl.data_ptr(), None, dm.data_ptr(), dw2p.data_ptr(),
-                                              row.numel(), HEp, nblk, _s()))
+        L.check(lib.dvae_pair_bce_bwd_grouped(off.data_ptr(), row.data_ptr(), pairs.data_ptr(), dl.data_ptr(),
+                                              mask.data_ptr(), w2.data_ptr(), None, dm.data_ptr(), row.numel(), HEp,
+                                              _s()))
         assert (dm - gref).abs().max() < 1e-4
-        assert (dw2p.sum(0) - w2.grad).abs().max() < 1e-3
     assert (ea.grad.sum(0) - b1.grad).abs().max() < 1e-3  # db1 = column sum of dEA
+
+
+@pytest.mark.parametrize("HEp", [128, 384, 2048, 4096])
+def test_pair_kernels_widths(HEp):
+    """every compiled width class of the pair kernels (1, 2, 8, 16 column iterations; 1 or 2 mask words)"""
+    torch.manual_seed(HEp)
+    NA, NB, NP = 9, 10, 60
+    ea = torch.randn(NA, HEp, device="cuda", requires_grad=True)
+    eb = torch.randn(NB, HEp, device="cuda", requires_grad=True)
+    ec = torch.randn(5, HEp, device="cuda", requires_grad=True)
+    b1 = torch.randn(HEp, device="cuda")
+    w2 = (torch.randn(HEp, device="cuda") / HEp ** 0.5).requires_grad_(True)
+    b2 = torch.randn(1, device="cuda")
+    pa = torch.randint(0, NA, (NP,), device="cuda")
+    ph = torch.randint(0, NB, (NP,), device="cuda")
+    pc = torch.sort(torch.randint(0, 5, (NP,), device="cuda"))[0]
+    tgt = torch.randint(0, 2, (NP,), device="cuda")
+    s = (torch.relu(ea[pa] + eb[ph] + ec[pc] + b1) * w2).sum(1) + b2
+    ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(s), tgt.float(), reduction="sum")
+    ref.backward()
+    lib = L.load()
+    dl = torch.zeros(NP, device="cuda")
+    lsum = torch.zeros(1, device="cuda")
+    mask = torch.zeros(int(lib.dvae_pair_mask_words(NP, HEp)), dtype=torch.int32, device="cuda")
+    dw2p = torch.zeros(4, HEp, device="cuda")
+    pa_i, ph_i, pc_i, tgt_u = pa.int(), ph.int(), pc.int(), tgt.to(torch.uint8)
+    L.check(lib.dvae_pair_bce_fwd(ea.data_ptr(), eb.data_ptr(), ec.data_ptr(), pa_i.data_ptr(), ph_i.data_ptr(),
+                                  pc_i.data_ptr(), tgt_u.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                  dl.data_ptr(), lsum.data_ptr(), mask.data_ptr(), dw2p.data_ptr(), 4, NP, HEp, _s()))
+    assert abs(lsum.item() - ref.item()) < 1e-4 * ref.item()
+    assert (dw2p.sum(0) - w2.grad).abs().max() < 1e-4
+    # by graph: pairs are contiguous per graph (grp_pairs NULL), one chunk per graph
+    cnt = torch.bincount(pc.cpu(), minlength=5)
+    off = torch.zeros(6, dtype=torch.int32)
+    off[1:] = cnt.cumsum(0)
+    rows = torch.arange(5, dtype=torch.int32).cuda()
+    off_d = off.cuda()
+    dc = torch.zeros(5, HEp, device="cuda")
+    L.check(lib.dvae_pair_bce_bwd_grouped(off_d.data_ptr(), rows.data_ptr(), None, dl.data_ptr(), mask.data_ptr(),
+                                          w2.data_ptr(), None, dc.data_ptr(), 5, HEp, _s()))
+    assert (dc - ec.grad).abs().max() < 1e-4
 
 
 def test_vertex_ce_matches_torch():
