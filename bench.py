@@ -199,8 +199,10 @@ def main():
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     model = make_model(cfg, mfma_dtype="bf16" if bf16 else "fp32").to(dev)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)  # same update rule, one multi-tensor launch
+    # flat gradient buffer (its slices are the parameters' .grad; backward adds into them in place) and
+    # Adam as one launch over the flat parameter buffer: the update rule of train.py:174
     reducer = dvae_amd.dist.GradSumReducer(model)
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
 
     # pre-packed batches: weak scaling, every rank owns B graphs per step
     B = cfg["B"]

@@ -17,6 +17,7 @@ constexpr int MAX_OPS = 48;
 struct CopyOps {
     CopyOp op[MAX_OPS];
     int n;
+    int accumulate;  // dst += src
 };
 
 __global__ void copy_ops_kernel(CopyOps ops) {
@@ -24,7 +25,9 @@ __global__ void copy_ops_kernel(CopyOps ops) {
     long total = (long)o.rows * o.cols;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / o.cols), c = (int)(i % o.cols);
-        o.dst[(long)r * o.dst_ld + c] = o.src[(long)r * o.src_ld + c];
+        float v = o.src[(long)r * o.src_ld + c];
+        float* d = o.dst + (long)r * o.dst_ld + c;
+        *d = ops.accumulate ? *d + v : v;
     }
 }
 
@@ -36,19 +39,21 @@ __global__ void build_gi_kernel(float* gi, const float* wih, const float* bih, c
     float v = wih[(long)r * T + t] + bih[r] + (q < 2 ? bhh[r] : 0.f);
     gi[(long)t * 3 * Hp + q * Hp + j] = v;
 }
+__device__ __forceinline__ void put(float* d, float v, int acc) { *d = acc ? *d + v : v; }
+
 __global__ void unbuild_gi_kernel(const float* dgi, const float* dbhn, float* dwih, float* dbih, float* dbhh, int T,
-                                  int H, int Hp) {
+                                  int H, int Hp, int acc) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= 3 * H) return;
     int q = r / H, j = r % H;
     float s = 0.f;
     for (int t = 0; t < T; ++t) {
         float v = dgi[(long)t * 3 * Hp + q * Hp + j];
-        if (dwih) dwih[(long)r * T + t] = v;
+        if (dwih) put(dwih + (long)r * T + t, v, acc);
         s += v;
     }
-    if (dbih) dbih[r] = s;
-    if (dbhh) dbhh[r] = q < 2 ? s : dbhn[j];
+    if (dbih) put(dbih + r, s, acc);
+    if (dbhh) put(dbhh + r, q < 2 ? s : dbhn[j], acc);
 }
 
 // gv[v][j] = (vid ? Wg[j][H+v] : 0) + bg[j];  gv[v][Hp+j] = vid ? Wm[j][H+v] : 0
@@ -61,7 +66,7 @@ __global__ void build_gv_kernel(float* gv, const float* wg, const float* bg, con
     gv[(long)v * 2 * Hp + Hp + j] = vid ? wm[(long)j * V + H + v] : 0.f;
 }
 __global__ void unbuild_gv_kernel(const float* dgv, float* dwg, float* dbg, float* dwm, int n, int H, int Hp, int V,
-                                  int vid) {
+                                  int vid, int acc) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     float s = 0.f;
@@ -69,11 +74,11 @@ __global__ void unbuild_gv_kernel(const float* dgv, float* dwg, float* dbg, floa
         float a = dgv[(long)v * 2 * Hp + j];
         s += a;
         if (vid) {
-            if (dwg) dwg[(long)j * V + H + v] = a;
-            if (dwm) dwm[(long)j * V + H + v] = dgv[(long)v * 2 * Hp + Hp + j];
+            if (dwg) put(dwg + (long)j * V + H + v, a, acc);
+            if (dwm) put(dwm + (long)j * V + H + v, dgv[(long)v * 2 * Hp + Hp + j], acc);
         }
     }
-    if (dbg) dbg[j] = s;
+    if (dbg) put(dbg + j, s, acc);
 }
 
 // BN message table: gated(u) = sigmoid(Wg[:, t_u] + bg) * Wm[:, t_u]  (models.py:1044-1062)
@@ -89,7 +94,7 @@ __global__ void build_bn_table_kernel(float* gtab, float* gtg, float* gtm, const
     gtab[(long)t * Hp + j] = g * m;
 }
 __global__ void unbuild_bn_table_kernel(const float* dgtab, const float* gtg, const float* gtm, float* dwg, float* dbg,
-                                        float* dwm, int T, int H, int Hp) {
+                                        float* dwm, int T, int H, int Hp, int acc) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     float s = 0.f;
@@ -97,10 +102,10 @@ __global__ void unbuild_bn_table_kernel(const float* dgtab, const float* gtg, co
         float d = dgtab[(long)t * Hp + j], g = gtg[(long)t * Hp + j], m = gtm[(long)t * Hp + j];
         float da = d * m * g * (1.f - g);
         s += da;
-        if (dwg) dwg[(long)j * T + t] = da;
-        if (dwm) dwm[(long)j * T + t] = d * g;
+        if (dwg) put(dwg + (long)j * T + t, da, acc);
+        if (dwm) put(dwm + (long)j * T + t, d * g, acc);
     }
-    if (dbg) dbg[j] = s;
+    if (dbg) put(dbg + j, s, acc);
 }
 
 // native <-> packed block copies.  `nat[i]` may be null (absent parameter).
@@ -108,6 +113,7 @@ __global__ void unbuild_bn_table_kernel(const float* dgtab, const float* gtg, co
 static int block_ops(const Dims& d, const PackedLayout& L, float* const* nat, float* pk, bool to_packed, CopyOps& ops,
                      const bool* want /* nullable: which params to touch */) {
     ops.n = 0;
+    ops.accumulate = 0;
     const int H = d.H, Hp = d.Hp;
     auto add = [&](int pid, size_t nat_off, int nat_ld, size_t pk_off, int pk_ld, int rows, int cols) {
         if (!nat[pid] || (want && !want[pid])) return;
@@ -227,8 +233,9 @@ extern "C" int dvae_pack_weights(const dvae_model_desc* m, const float* const* p
 
 // packed gradient buffer -> native gradient tensors.  `want[i]` != 0 selects the
 // parameters this call produces (others untouched); grads[i] may be null.
+// accumulate != 0: grads[i] += (PyTorch's .grad accumulation, done in place).
 extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const float* packed_g,
-                                 float* const* grads, const uint8_t* want, void* stream) {
+                                 float* const* grads, const uint8_t* want, int32_t accumulate, void* stream) {
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_REQUIRE(packed_g && grads && want, "dvae_unpack_grads: null pointer");
@@ -238,6 +245,8 @@ extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w
     for (int i = 0; i < P_COUNT; ++i) w[i] = want[i] != 0 && grads[i] != nullptr;
     CopyOps ops;
     DVAE_TRY(block_ops(d, L, grads, const_cast<float*>(packed_g), false, ops, w));
+    ops.accumulate = accumulate != 0;
+    const int acc = accumulate != 0;
     DVAE_TRY(run_ops(ops, s));
     const int wih[3] = {P_EF_WIH, P_EB_WIH, P_D_WIH};
     for (int g = 0; g < 3; ++g) {
@@ -245,7 +254,7 @@ extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w
         if (!(w[a] || w[a + 2] || w[a + 3])) continue;
         hipLaunchKernelGGL(unbuild_gi_kernel, dim3(cdiv(3 * d.H, 256)), dim3(256), 0, s, packed_g + L.gi[g],
                            packed_g + L.bhn[g], w[a] ? grads[a] : nullptr, w[a + 2] ? grads[a + 2] : nullptr,
-                           w[a + 3] ? grads[a + 3] : nullptr, d.T, d.H, d.Hp);
+                           w[a + 3] ? grads[a + 3] : nullptr, d.T, d.H, d.Hp, acc);
     }
     const int gw[2] = {P_GF_W, P_GB_W}, gb[2] = {P_GF_B, P_GB_B}, mw[2] = {P_MF_W, P_MB_W};
     for (int k = 0; k < 2; ++k) {
@@ -256,10 +265,10 @@ extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w
         if (d.bn) {
             DVAE_REQUIRE(packed_w != nullptr, "dvae_unpack_grads: BN needs the packed weights (gate tables)");
             hipLaunchKernelGGL(unbuild_bn_table_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gtab[k],
-                               packed_w + L.gtg[k], packed_w + L.gtm[k], dwg, dbg, dwm, d.T, d.H, d.Hp);
+                               packed_w + L.gtg[k], packed_w + L.gtm[k], dwg, dbg, dwm, d.T, d.H, d.Hp, acc);
         } else {
             hipLaunchKernelGGL(unbuild_gv_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gv[k], dwg, dbg,
-                               dwm, d.n, d.H, d.Hp, d.V, d.vid);
+                               dwm, d.n, d.H, d.Hp, d.V, d.vid, acc);
         }
     }
     DVAE_LAUNCH_CHECK();

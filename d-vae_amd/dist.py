@@ -21,17 +21,25 @@ class GradSumReducer(object):
     encoder's when unidirectional) keep grad=None, as in the reference, so the
     optimizer skips them identically on every rank."""
 
-    def __init__(self, model, live_names=None):
+    def __init__(self, model, live_names=None, sink=True):
         named = dict(model.named_parameters())
         if live_names is None:
             live_names = list(dict.fromkeys(list(model._enc_names) + list(model._dec_names)))
         self.params = [named[k] for k in live_names]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.names = list(live_names)
+        # every slice starts on a 256-byte boundary (vector loads / stores of the optimizer kernel)
+        self.offsets = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            self.offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.params[0].device)
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        # backward() then adds straight into these views (no autograd accumulation kernels)
+        if sink and hasattr(model, "attach_grad_sink") and self.flat.is_cuda:
+            model.attach_grad_sink(True)
 
     def zero(self):
         self.flat.zero_()

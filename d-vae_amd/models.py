@@ -193,6 +193,7 @@ class DVAE(nn.Module):
         self._pw = None
         self._pw_key = None
         self._named_cache = None
+        self._grad_sink = getattr(self, "_grad_sink", False)
         self._enc_names = _ENC_FWD + (_ENC_BWD if self.bidir else [])
         self._dec_names = list(_DEC)
         self.eps_override = None  # test hook: fixed normal draw for reparameterize
@@ -241,21 +242,40 @@ class DVAE(nn.Module):
         return pw
 
     def _unpack(self, pw, pg, names):
+        """Packed gradient buffer -> gradients of `names`.  Default: fresh tensors, returned to
+        autograd.  With a gradient sink attached (`attach_grad_sink`): added in place to the
+        parameters' existing .grad storage and None is returned for each, so autograd runs no
+        accumulation kernels of its own."""
         lib = _lib.load()
         named = self._named()
         ptrs = [None] * _lib.NUM_PARAMS
         want = [0] * _lib.NUM_PARAMS
         grads = []
+        sink = self._grad_sink
         for k in names:
-            g = torch.empty_like(named[k])
-            grads.append(g)
+            if sink:
+                g = named[k].grad
+                if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.device != pg.device:
+                    raise _lib.DvaeHipError("gradient sink: %s has no contiguous float32 .grad on %s" % (k, pg.device))
+                grads.append(None)
+            else:
+                g = torch.empty_like(named[k])
+                grads.append(g)
             ptrs[_IDX[k]] = g.data_ptr()
             want[_IDX[k]] = 1
         arr = (C.c_void_p * _lib.NUM_PARAMS)(*ptrs)
         w = (C.c_uint8 * _lib.NUM_PARAMS)(*want)
-        _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), arr, w, _stream()),
-                   "dvae_unpack_grads")
+        _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), arr, w, int(bool(sink)),
+                                         _stream()), "dvae_unpack_grads")
         return grads
+
+    def attach_grad_sink(self, on=True):
+        """Gradient sink: backward() adds the gradients of the hot-path parameters straight into
+        their preallocated .grad tensors (e.g. the views of `dist.GradSumReducer`'s flat buffer)
+        instead of returning them to autograd.  Same .grad contents after loss.backward(); the
+        difference is only visible to torch.autograd.grad(), which then sees no gradient."""
+        self._grad_sink = bool(on)
+        return self
 
     def _as_batch(self, G):
         if isinstance(G, DAGBatch):

@@ -179,9 +179,16 @@ int64_t dvae_packed_floats(const dvae_model_desc* m);
 /* native parameters -> packed buffer (call after every optimizer step) */
 int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream);
 /* packed gradient buffer -> native gradient tensors; want[i] != 0 selects which
- * of grads[0..DVAE_NUM_PARAMS) are written (fully overwritten). */
+ * of grads[0..DVAE_NUM_PARAMS) are written: fully overwritten, or, with accumulate != 0, added to
+ * in place (PyTorch's .grad accumulation without a temporary). */
 int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const float* packed_g, float* const* grads,
-                      const uint8_t* want, void* stream);
+                      const uint8_t* want, int32_t accumulate, void* stream);
+
+/* One Adam step over a flat fp32 buffer of n floats (n % 4 == 0; parameters, gradients and the
+ * two moments laid out alike): torch.optim.Adam's update as the reference configures it
+ * (train.py:174; no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
+int dvae_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t step, void* stream);
 
 /* ---------------------------------------------------------------------------
  * DAG batching (host).  Replaces models.py:631-632 (_collate_fn), the per-vertex

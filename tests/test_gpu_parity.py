@@ -232,3 +232,43 @@ def test_bf16_mode_close_to_oracle(cls, bidir, var):
     assert rel_err(mu, r64[3]) > 1e-5
     print("bf16 mode: loss rel %.2e, mu rel %.2e, worst grad rel %.2e"
           % (abs(loss.item() - r64[0].item()) / abs(r64[0].item()), rel_err(mu, r64[3]), worst))
+
+
+def test_grad_sink_and_flat_adam_match_autograd_and_torch_adam():
+    """(a) With the gradient sink, backward() leaves the same .grad as the autograd-returned path;
+    (b) FlatAdam == torch.optim.Adam (train.py:174) over several steps on those gradients."""
+    rng = np.random.default_rng(21)
+    n, T, hs, nz, B = 8, 8, 40, 8, 24
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=1)
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.3, True)
+    ga = dvae_amd.GraphArrays.from_dense(types, adj, n_g)
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    ref_model = make_model("DVAE", ctor, 9).cuda()
+    ref_opt = torch.optim.Adam(ref_model.parameters(), lr=1e-3)
+    model = make_model("DVAE", ctor, 9).cuda()
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-3)
+    assert model._grad_sink
+    for step in range(4):
+        ref_opt.zero_grad()
+        mu, lv = ref_model.encode(ga)
+        l_ref, _, _ = ref_model.loss(mu, lv, ga, eps=eps)
+        l_ref.backward()
+        opt.zero_grad()
+        mu, lv = model.encode(ga)
+        l, _, _ = model.loss(mu, lv, ga, eps=eps)
+        l.backward()
+        assert abs(l.item() - l_ref.item()) <= 2e-5 * abs(l_ref.item()), step
+        ref_g = dict(ref_model.named_parameters())
+        for k, p in model.named_parameters():
+            if ref_g[k].grad is None:
+                assert p.grad is None, k
+            else:
+                assert rel_err(p.grad, ref_g[k].grad) < 2e-5, (step, k)
+        ref_opt.step()
+        opt.step()
+        for k, p in model.named_parameters():
+            assert rel_err(p, ref_g[k]) < 2e-6, (step, k)
+    # state_dict is unchanged by the flat storage (same keys, shapes, values as the torch-Adam twin)
+    sd, sd_ref = model.state_dict(), ref_model.state_dict()
+    assert list(sd.keys()) == list(sd_ref.keys())
+    assert all(sd[k].shape == sd_ref[k].shape for k in sd)

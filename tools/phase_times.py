@@ -19,8 +19,8 @@ def main():
     cfg = bench.CONFIGS[name]
     dev = torch.device("cuda", 0)
     model = bench.make_model(cfg).to(dev).train()
-    opt = bench.make_optimizer(model) if hasattr(bench, "make_optimizer") else torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     reducer = dvae_amd.dist.GradSumReducer(model)
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
     B = cfg["B"]
     batches = [model._collate_fn(bench.make_graphs(cfg, B, seed=i)) for i in range(4)]
     eps = [torch.randn(B, cfg["nz"], device=dev) for _ in range(4)]
