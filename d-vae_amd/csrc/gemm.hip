@@ -357,13 +357,31 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     int ksteps = cdiv(d.K, BK);
     const bool small_m = d.M <= 32 && d.a_kmajor;
     if (d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 8) {
-        long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
-        long target = use128 && !small_m ? 512 : 768;
-        int want = (int)((target + tiles - 1) / tiles);
-        int maxsplit = ksteps / 4;
-        int sk = want < maxsplit ? want : maxsplit;
-        if (sk > 1) {
-            p.k_per_split = cdiv(ksteps, sk) * BK;
+        // Split choice, fitted to measurements on MI355X (tools/gemm_quant.py, tools/gemm_bench.py):
+        // run time advances in whole ROUNDS of 256 workgroups (a launch of 528 costs as much as one
+        // of 768).  128x128 tiles: two workgroups per CU hide each other's load latency, so fill
+        // 512 slots without overshooting; with more than one round of tiles already, pick the split
+        // that minimises rounds x (K steps + ~5 steps of prologue and atomic epilogue).  64x64 tiles
+        // (four fit on a CU): three per CU.
+        const long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
+        const int maxsplit = ksteps / 4;
+        int best = 1;
+        if (use128 && !small_m && tiles <= 256) {
+            best = (int)(512 / tiles);
+        } else if (use128 && !small_m) {
+            long best_cost = -1;
+            for (int sk = 1; sk <= 16; ++sk) {
+                const long rounds = (tiles * sk + 255) / 256;
+                const long cost = rounds * (cdiv(ksteps, sk) + 5);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sk; }
+            }
+        } else {
+            best = (int)((768 + tiles - 1) / tiles);
+        }
+        if (best > maxsplit) best = maxsplit;
+        if (best < 1) best = 1;
+        if (best > 1) {
+            p.k_per_split = cdiv(ksteps, best) * BK;
             p.split_k = cdiv(d.K, p.k_per_split);
         }
     }
