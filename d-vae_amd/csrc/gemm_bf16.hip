@@ -270,7 +270,7 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     const bool small_m = d.M <= 32 && d.a_kmajor;
     if (d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 4) {
         long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
-        long target = use128 && !small_m ? 512 : 768;
+        long target = use128 && !small_m ? 512 : 256;  // small tiles: measured best at one workgroup per CU
         int want = (int)((target + tiles - 1) / tiles);
         int maxsplit = ksteps / 2;
         int sk = want < maxsplit ? want : maxsplit;
