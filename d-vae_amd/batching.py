@@ -51,6 +51,11 @@ class GraphArrays(object):
             adj[:, u, :] = ((self.pred_mask >> np.uint64(u)) & np.uint64(1)).astype(np.uint8)
         return self.types.astype(np.int64), adj, self.n_vertices.astype(np.int64)
 
+    def to_graphs(self):
+        """-> list of graph.DAG (the igraph-like container decode() also returns)"""
+        from .graph import DAG
+        return [DAG.from_arrays(self.types[i], self.pred_mask[i], self.n_vertices[i]) for i in range(len(self))]
+
     @staticmethod
     def from_dense(types, adj, n_g):
         types = np.asarray(types)

@@ -108,3 +108,215 @@ def synth_bn_rows(count, n_vars=8, p_edge=0.25, seed=0):
         rng.shuffle(order)
         rows.append([[t] + [1 if rng.random() < p_edge else 0 for _ in range(i)] for i, t in enumerate(order)])
     return rows
+
+
+# ---------------------------------------------------------------------------------------------
+# Data-set loaders and row <-> graph codecs (reference `util.py:64-296`), igraph-free.
+# Rows are parsed with ast.literal_eval (the reference eval()s them).
+# ---------------------------------------------------------------------------------------------
+import os
+from types import SimpleNamespace
+
+from .graph import DAG, IN as _IN
+
+
+def decode_ENAS_to_igraph(row):
+    """ENAS row -> (DAG, n_vertices); `util.py:128-144`.  Vertex ids are a topological order."""
+    row = parse_row(row)
+    n = len(row)
+    g = DAG()
+    g.add_vertices(n + 2)
+    g.vs[0]["type"] = 0
+    for i, node in enumerate(row):
+        g.vs[i + 1]["type"] = node[0] + 2
+        g.add_edge(i, i + 1)
+        for j, e in enumerate(node[1:]):
+            if e == 1:
+                g.add_edge(j, i + 1)
+    g.vs[n + 1]["type"] = 1
+    g.add_edge(n, n + 1)
+    return g, n + 2
+
+
+def decode_BN_to_igraph(row):
+    """Bayesian-network row -> (DAG, n_vertices); `util.py:255-275`."""
+    row = parse_row(row)
+    n = len(row)
+    g = DAG()
+    g.add_vertices(n + 2)
+    g.vs[0]["type"] = 0
+    for i, node in enumerate(row):
+        g.vs[i + 1]["type"] = node[0] + 2
+        if sum(node[1:]) == 0:
+            g.add_edge(0, i + 1)
+        else:
+            for j, e in enumerate(node[1:]):
+                if e == 1:
+                    g.add_edge(j + 1, i + 1)
+    g.vs[n + 1]["type"] = 1
+    for j in [v.index for v in g.vs.select(_outdegree_eq=0) if v.index != n + 1]:
+        g.add_edge(j, n + 1)
+    return g, n + 2
+
+
+def flat_ENAS_to_nested(row, n_nodes):
+    """'4 0 1 3 1 0 ...' -> [[4], [0, 1], [3, 1, 0], ...]; `util.py:147-158`."""
+    if isinstance(row, str):
+        row = [int(x) for x in row.split()]
+    cnt, res = 0, []
+    for i in range(1, n_nodes + 1):
+        res.append(row[cnt:cnt + i])
+        cnt += i
+        if cnt == len(row):
+            break
+    return res
+
+
+def decode_igraph_to_ENAS(g):
+    """graph -> flattened ENAS string (types - 2, optional-edge flags); `util.py:161-173`."""
+    n = g.vcount()
+    res = []
+    adjlist = g.get_adjlist(_IN)
+    for i in range(1, n - 1):
+        res.append(int(g.vs[i]["type"]) - 2)
+        row = [0] * (i - 1)
+        for j in adjlist[i]:
+            if j < i - 1:
+                row[j] = 1
+        res += row
+    return " ".join(str(x) for x in res)
+
+
+def decode_igraph_to_BN_adj(g):
+    """BN graph -> flattened adjacency string in variable order; `util.py:278-284`."""
+    types = g.vs["type"][1:-1]
+    order = np.argsort(types).tolist()
+    adj = np.array(g.get_adjacency().data)[1:-1, 1:-1]
+    adj = adj[order][:, order]
+    return " ".join(str(x) for x in adj.reshape(-1))
+
+
+def adjstr_to_BN(row, n_vars=8):
+    """flattened adjacency string -> BN row format; `util.py:287-296`."""
+    matrix = np.array([int(x) for x in row.split()]).reshape(n_vars, n_vars)
+    res = [[0]]
+    for i in range(1, n_vars):
+        res.append([i] + matrix[:i, i].tolist())
+    return res
+
+
+def _load_rows(path, with_y, burn_in):
+    rows, ys = [], []
+    with open(path, "r") as f:
+        for i, line in enumerate(f):
+            if i < burn_in:
+                continue
+            line = line.strip()
+            if not line:
+                continue
+            val = ast.literal_eval(line)
+            if with_y:
+                row, y = val
+            else:
+                row, y = val, 0.0
+            rows.append(row)
+            ys.append(float(y))
+    return rows, ys
+
+
+def _split(items, ys, rand_seed):
+    """the reference's 90/10 split: random.Random(seed).shuffle of the (g, y) list"""
+    order = list(range(len(items)))
+    random.Random(rand_seed).shuffle(order)
+    cut = int(len(order) * 0.9)
+    return order[:cut], order[cut:]
+
+
+def _finish(rows, ys, decode, to_arrays, fmt, max_n, rand_seed):
+    tr, te = _split(rows, ys, rand_seed)
+    if fmt == "igraph":
+        graphs = [decode(r)[0] for r in rows]
+        return [(graphs[i], ys[i]) for i in tr], [(graphs[i], ys[i]) for i in te]
+    if fmt == "arrays":
+        ga = to_arrays(rows, max_n)
+        y = np.asarray(ys, np.float64)
+        return (ga.select(tr), y[tr]), (ga.select(te), y[te])
+    raise ValueError("fmt must be 'igraph' (DAG objects) or 'arrays' (pre-packed GraphArrays)")
+
+
+def load_ENAS_graphs(name, n_types=6, fmt="igraph", rand_seed=0, with_y=True, burn_in=1000, data_dir="data"):
+    """`util.py:64-93`: reads data/<name>.txt (rows `[[t0],[t1,e],...], y`), skips `burn_in` rows,
+    returns (train, test, graph_args) with the reference's shuffle and 90/10 split.
+    fmt='igraph': lists of (DAG, y);  fmt='arrays': (GraphArrays, y[]) pairs, the pre-packed form
+    the models take directly."""
+    rows, ys = _load_rows(os.path.join(data_dir, "%s.txt" % name), with_y, burn_in)
+    max_n = max(len(r) for r in rows) + 2
+    graph_args = SimpleNamespace(num_vertex_type=n_types + 2, max_n=max_n, START_TYPE=0, END_TYPE=1)
+    train, test = _finish(rows, ys, decode_ENAS_to_igraph, enas_rows_to_arrays, fmt, max_n, rand_seed)
+    return train, test, graph_args
+
+
+def load_BN_graphs(name, n_types=8, fmt="igraph", rand_seed=0, with_y=True, data_dir="data"):
+    """`util.py:190-223`: Bayesian-network rows, no burn-in, all graphs of one size."""
+    rows, ys = _load_rows(os.path.join(data_dir, "%s.txt" % name), with_y, 0)
+    sizes = set(len(r) for r in rows)
+    if len(sizes) != 1:
+        raise ValueError("all Bayesian networks must have the same number of nodes (found %s)" % sorted(sizes))
+    max_n = sizes.pop() + 2
+    graph_args = SimpleNamespace(num_class=1, num_vertex_type=n_types + 2, max_n=max_n, START_TYPE=0, END_TYPE=1)
+    train, test = _finish(rows, ys, decode_BN_to_igraph, bn_rows_to_arrays, fmt, max_n, rand_seed)
+    return train, test, graph_args
+
+
+# ---------------------------------------------------------------------------------------------
+# Validity / novelty predicates on decoded graphs (reference `util.py:466-539`)
+# ---------------------------------------------------------------------------------------------
+def is_same_DAG(g0, g1):
+    """same vertex types and predecessor sets, vertex by vertex (no isomorphism test)"""
+    if g0.vcount() != g1.vcount():
+        return False
+    for vi in range(g0.vcount()):
+        if g0.vs[vi]["type"] != g1.vs[vi]["type"]:
+            return False
+        if set(g0.neighbors(vi, "in")) != set(g1.neighbors(vi, "in")):
+            return False
+    return True
+
+
+def ratio_same_DAG(G0, G1):
+    """fraction of G1 that also occurs in G0"""
+    def key(g):
+        return (tuple(g.vs["type"]), tuple(tuple(sorted(p)) for p in g.get_adjlist(_IN)))
+    known = set(key(g) for g in G0)
+    return sum(1 for g in G1 if key(g) in known) / max(len(G1), 1)
+
+
+def is_valid_DAG(g, START_TYPE=0, END_TYPE=1):
+    res = g.is_dag()
+    n_start, n_end = 0, 0
+    for v in g.vs:
+        if v["type"] == START_TYPE:
+            n_start += 1
+        elif v["type"] == END_TYPE:
+            n_end += 1
+        if v.indegree() == 0 and v["type"] != START_TYPE:
+            return False
+        if v.outdegree() == 0 and v["type"] != END_TYPE:
+            return False
+    return res and n_start == 1 and n_end == 1
+
+
+def is_valid_ENAS(g, START_TYPE=0, END_TYPE=1):
+    res = is_valid_DAG(g, START_TYPE, END_TYPE)
+    for i in range(g.vcount() - 2):
+        res = res and g.are_connected(i, i + 1)
+        if not res:
+            return res
+    return res and (g.vs[g.vcount() - 1].indegree() == 1)
+
+
+def is_valid_BN(g, START_TYPE=0, END_TYPE=1, nvt=10):
+    res = g.is_dag()
+    types = g.vs["type"]
+    res = res and types.count(START_TYPE) == 1 and types.count(END_TYPE) == 1
+    return res and len(set(types)) == nvt and g.vcount() == nvt
