@@ -12,6 +12,7 @@
 #include "common.h"
 #include "model.h"
 #include "batch.h"
+#include "orch.h"
 #include <mutex>
 
 namespace dvae {
@@ -100,37 +101,6 @@ __global__ void sum_scaled_kernel(const float* x, int n, const float* scale, flo
         }                                                                                                \
     } while (0)
 
-// ------------------------------------------------------------------ gemm shorthands
-// Matrix-unit input type of the call in progress (dvae_model_desc.mfma_bf16), set by every
-// entry point before it enqueues anything.
-static thread_local int tl_bf16 = 0;
-static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s) { return tl_bf16 ? gemm_bf16(g, s) : gemm(g, s); }
-
-// Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
-static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
-                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s) {
-    dvae_gemm_desc g = {};
-    g.A = X; g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
-    g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc;
-    return run_gemm(g, s);
-}
-// dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)
-static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
-                     int N, int K, int acc, hipStream_t s) {
-    dvae_gemm_desc g = {};
-    g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
-    g.M = M; g.N = K; g.K = N; g.accumulate = acc;
-    return run_gemm(g, s);
-}
-// dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
-static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
-                     int N, int K, hipStream_t s) {
-    dvae_gemm_desc g = {};
-    g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
-    g.M = N; g.N = K; g.K = M; g.accumulate = 1;
-    return run_gemm(g, s);
-}
-
 // ------------------------------------------------------------------ side stream
 // The two encoder directions are independent chains of small dependent launches
 // (a level's GEMM fills at most half the chip).  They run concurrently: direction 0 on
@@ -167,17 +137,6 @@ static int join_side(Side* sd, hipStream_t main) {
     DVAE_HIP(hipStreamWaitEvent(main, sd->join, 0));
     return DVAE_OK;
 }
-
-// ------------------------------------------------------------------ workspaces
-struct Bump {
-    float* base;
-    size_t off;
-    float* take(size_t n) {
-        float* p = base ? base + off : nullptr;
-        off += (n + 63) & ~(size_t)63;
-        return p;
-    }
-};
 
 struct EncWs {
     float *agg[2], *gates[2], *ghn[2], *hs[2], *gm[2], *msg[2];

@@ -346,14 +346,56 @@ class DVAE(nn.Module):
         loss, _, _ = self.loss(mu, logvar, batch)
         return loss
 
-    def decode(self, z, stochastic=True):
-        raise NotImplementedError("decode() is outside the train-step hot path (SURVEY.md 8f row N1)")
+    def decode_arrays(self, z, stochastic=True, uniforms=None):
+        """decode() without the host-side graph objects: returns a GraphArrays (types,
+        predecessor masks, sizes).  `uniforms` = (u_type [B, max_n], u_edge [B, max_n, max_n])
+        injects the random draws; default: torch.rand on the device."""
+        lib = _lib.load()
+        pw = self._packed_weights()
+        dev = pw.device
+        z = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if z.dim() != 2 or z.shape[1] != self.nz:
+            raise ValueError("z must be [B, %d]" % self.nz)
+        B, n = z.shape[0], self.max_n
+        if B == 0:
+            return GraphArrays(torch.zeros(0, n).numpy(), torch.zeros(0, n).numpy(), torch.zeros(0).numpy(), n)
+        u_type = u_edge = None
+        if stochastic:
+            if uniforms is None:
+                u_type = torch.rand(B, n, device=dev, dtype=torch.float32)
+                u_edge = torch.rand(B, n, n, device=dev, dtype=torch.float32)
+            else:
+                u_type = torch.as_tensor(uniforms[0]).to(device=dev, dtype=torch.float32).contiguous()
+                u_edge = torch.as_tensor(uniforms[1]).to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(u_type.shape) != (B, n) or tuple(u_edge.shape) != (B, n, n):
+                    raise ValueError("uniforms must be ([B, max_n], [B, max_n, max_n])")
+        n_ws = lib.dvae_decode_ws_floats(C.byref(self._desc), B)
+        if n_ws < 0:
+            _lib.check(-1, "dvae_decode_ws_floats")
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        types = torch.empty(B, n, dtype=torch.int32, device=dev)
+        pmask = torch.empty(B, n, dtype=torch.int64, device=dev)
+        n_g = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.dvae_decode(C.byref(self._desc), B, pw.data_ptr(), ws.data_ptr(), z.data_ptr(), int(bool(stochastic)),
+                                   u_type.data_ptr() if stochastic else None, u_edge.data_ptr() if stochastic else None,
+                                   types.data_ptr(), pmask.data_ptr(), n_g.data_ptr(), _stream()), "dvae_decode")
+        return GraphArrays(types.cpu().numpy(), pmask.cpu().numpy().view("uint64"), n_g.cpu().numpy(), n)
+
+    def decode(self, z, stochastic=True, uniforms=None):
+        """Latent points -> list of graphs (reference `models.py:747-804`).  The graphs are
+        `graph.DAG` objects (igraph's surface: vcount, vs['type'], get_adjlist, ...)."""
+        return self.decode_arrays(z, stochastic, uniforms).to_graphs()
 
     def encode_decode(self, G):
-        raise NotImplementedError("encode_decode() is outside the train-step hot path (SURVEY.md 8f row N1)")
+        """reference `models.py:862-865`"""
+        mu, logvar = self.encode(G)
+        z = self.reparameterize(mu, logvar)
+        return self.decode(z)
 
     def generate_sample(self, n):
-        raise NotImplementedError("generate_sample() is outside the train-step hot path (SURVEY.md 8f row N1)")
+        """reference `models.py:872-875`"""
+        sample = torch.randn(n, self.nz).to(self.get_device())
+        return self.decode(sample)
 
 
 class DVAE_BN(DVAE):

@@ -247,6 +247,22 @@ int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_counts* c, con
                        int32_t training, float beta, const float* g3, float* dmu, float* dlogvar, float* pg,
                        void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Generation.  DVAE.decode, models.py:747-804 (DVAE_BN inherits it, with the
+ * helpers of models.py:1006-1085): B latent points z [B][nz] -> B DAGs, grown
+ * vertex by vertex entirely on the device.  Outputs (device): types [B][max_n],
+ * pred_mask [B][max_n] (bit u of pred_mask[b][v] <=> edge u -> v), n_vertices [B].
+ * stochastic != 0: the vertex type is an inverse-CDF sample of the softmax with
+ * u_type[b][idx] (the rule of np.random.choice, models.py:766) and edge vi -> idx
+ * is taken iff u_edge[b][idx][vi] < probability (models.py:783-784); both arrays
+ * hold uniforms in [0, 1), shapes [B][max_n] and [B][max_n][max_n].
+ * stochastic == 0: argmax type, edge iff probability > 0.5 (u_* may be NULL).
+ * ------------------------------------------------------------------------- */
+int64_t dvae_decode_ws_floats(const dvae_model_desc* m, int32_t B);
+int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw, float* ws, const float* z, int32_t stochastic,
+                const float* u_type, const float* u_edge, int32_t* types, uint64_t* pred_mask, int32_t* n_vertices,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@ reference algorithm in /root/reference/models.py:
   * `reparameterize`    follows DVAE.reparameterize    models.py:733-740
   * `_edge_score`       follows _get_edge_score        models.py:742-745 (BN 1082-1085)
   * `_graph_state_*`    follow _get_graph_state        models.py:704-718 (BN 1006-1027)
+  * `decode`            follows DVAE.decode            models.py:747-804 (the random draws
+                        of np.random.choice :766 and torch.rand_like :783 injected as uniforms)
 
 Two evaluation modes that must agree (tests check it):
 
@@ -374,6 +376,83 @@ def loss_refstyle(cfg, sd, mu, logvar, types, adj, n_g, eps, beta=0.005, trainin
     res = -res
     kld = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
     return res + beta * kld, res, kld
+
+
+# ----------------------------------------------------------------------------
+# generation (models.py:747-804)
+# ----------------------------------------------------------------------------
+def choice_from_uniform(probs, u):
+    """np.random.choice(range(len(p)), p=p) for ONE uniform draw u in [0, 1): numpy's legacy
+    generator builds the float64 CDF, normalises it by its last entry and takes
+    cdf.searchsorted(u, side='right')."""
+    import numpy as np
+    cdf = np.asarray(probs, dtype=np.float64).cumsum()
+    cdf /= cdf[-1]
+    return int(min(cdf.searchsorted(float(u), side="right"), len(cdf) - 1))
+
+
+def decode(cfg, sd, z, stochastic=True, u_type=None, u_edge=None):
+    """DVAE.decode / DVAE_BN's inherited decode, graph by graph (decode has no cross-graph
+    coupling).  stochastic: vertex type = inverse-CDF sample with u_type[b, idx] (what
+    np.random.choice does with its uniform), edge vi -> idx iff u_edge[b, idx, vi] < score
+    (torch.rand_like(score) < score).  Returns types [B, n] int64, adj [B, n, n] uint8, n_g [B]."""
+    import numpy as np
+    B, n, dtype = z.shape[0], cfg.max_n, z.dtype
+    H0 = torch.tanh(_linear(sd, "fc3", z))
+    types_out = np.zeros((B, n), np.int64)
+    adj_out = np.zeros((B, n, n), np.uint8)
+    ng_out = np.zeros((B,), np.int64)
+
+    def agg(H, types, preds):
+        if not preds:
+            return torch.zeros(1, cfg.hs, dtype=dtype)
+        tot = 0
+        for u in preds:
+            tot = tot + _gated(sd, "forward", _msg_input(cfg, H[u], u, torch.tensor([types[u]]), dtype))
+        return tot
+
+    for b in range(B):
+        h0 = H0[b:b + 1]
+        types = [cfg.START_TYPE]
+        preds = [[]]
+        H = [_gru(sd, "grud", _one_hot(torch.tensor([cfg.START_TYPE]), cfg.nvt, dtype), h0)]
+        for idx in range(1, n):
+            if idx == n - 1:
+                t = cfg.END_TYPE
+            else:
+                Hg = torch.cat(H, 0).sum(0, keepdim=True) if cfg.is_bn else H[-1]
+                scores = _linear(sd, "add_vertex.2", torch.relu(_linear(sd, "add_vertex.0", Hg)))
+                if stochastic:
+                    probs = F.softmax(scores, 1)[0].detach().numpy()
+                    t = choice_from_uniform(probs, u_type[b, idx])
+                else:
+                    t = int(torch.argmax(scores, 1).item())
+            types.append(t)
+            preds.append([])
+            x = _one_hot(torch.tensor([t]), cfg.nvt, dtype)
+            Hcur = _gru(sd, "grud", x, agg(H, types, preds[idx]))
+            for vi in range(idx - 1, -1, -1):
+                if t == cfg.END_TYPE:
+                    # connect every loose end (out-degree 0) to the end vertex, then stop (:786-791)
+                    has_out = set(u for p in preds for u in p)
+                    preds[idx] = [u for u in range(idx) if u not in has_out]
+                    Hcur = _gru(sd, "grud", x, agg(H, types, preds[idx]))
+                    break
+                score = _edge_score(cfg, sd, H[vi], Hcur, h0)[0, 0].item()
+                take = (float(u_edge[b, idx, vi]) < score) if stochastic else (score > 0.5)
+                if take:
+                    preds[idx].append(vi)
+                Hcur = _gru(sd, "grud", x, agg(H, types, preds[idx]))
+            H.append(Hcur)
+            if t == cfg.END_TYPE:
+                break
+        k = len(types)
+        ng_out[b] = k
+        types_out[b, :k] = types
+        for v, pl in enumerate(preds):
+            for u in pl:
+                adj_out[b, u, v] = 1
+    return types_out, adj_out, ng_out
 
 
 # ----------------------------------------------------------------------------

@@ -12,7 +12,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_files(pattern="*"):
-    return sorted(glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+    """train-step fixtures by default; the generation fixtures are named decode_*"""
+    files = sorted(glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+    if not pattern.startswith("decode_"):
+        files = [f for f in files if not os.path.basename(f).startswith("decode_")]
+    return files
 
 
 def load_case(path):

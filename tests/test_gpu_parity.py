@@ -272,3 +272,62 @@ def test_grad_sink_and_flat_adam_match_autograd_and_torch_adam():
     sd, sd_ref = model.state_dict(), ref_model.state_dict()
     assert list(sd.keys()) == list(sd_ref.keys())
     assert all(sd[k].shape == sd_ref[k].shape for k in sd)
+
+
+# ---------------------------------------------------------------- generation (models.py:747-804)
+DECODE = golden_files("decode_*")
+
+
+@pytest.mark.parametrize("path", DECODE, ids=[os.path.basename(p)[:-4] for p in DECODE])
+def test_decode_matches_reference_golden(path):
+    """decode() on the GPU reproduces, graph for graph, what the REFERENCE decoded from the same
+    latent points and the same (replayed) random draws -- types, edges and sizes are integers:
+    exact match required."""
+    d, cls, ctor = load_case(path)
+    model = make_model(cls, ctor)
+    model.load_state_dict(state_dict_of(d))
+    model.cuda().eval()
+    stochastic = bool(int(d["stochastic"]))
+    ga = model.decode_arrays(torch.from_numpy(d["z"]), stochastic, (d["u_type"], d["u_edge"]))
+    types, adj, n_g = ga.to_dense()
+    assert np.array_equal(n_g, d["n_g"])
+    assert np.array_equal(types, d["types"])
+    assert np.array_equal(adj, d["adj"])
+    graphs = model.decode(torch.from_numpy(d["z"]), stochastic, (d["u_type"], d["u_edge"]))
+    assert len(graphs) == len(n_g) and all(g.vcount() == k for g, k in zip(graphs, n_g))
+    assert all(g.vs[0]["type"] == 0 and g.vs[g.vcount() - 1]["type"] == 1 and g.is_dag() for g in graphs)
+
+
+@pytest.mark.parametrize("cls", ["DVAE", "DVAE_BN"])
+def test_decode_random_matches_oracle_and_round_trips(cls):
+    """Seeded random weights at hs=72 (three column iterations in the edge kernel), 200 latent
+    points, stochastic: the oracle decodes the same graphs from the same draws (up to draws that
+    fall within fp32 rounding of a decision boundary: at most 1 % of graphs may differ), and the
+    decoded graphs feed straight back into encode()/loss()."""
+    rng = np.random.default_rng(5)
+    n, T, hs, nz, B = 9, 7, 72, 10, 200
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=0)
+    model = make_model(cls, ctor, 4)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.startswith(("add_vertex", "add_edge", "fc3")):
+                p.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    z = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    u_type = rng.random((B, n)).astype(np.float32)
+    u_edge = rng.random((B, n, n)).astype(np.float32)
+    t_o, a_o, n_o = O.decode(cfg_of(cls, ctor), sd, z, True, u_type, u_edge)
+    model.cuda().eval()
+    ga = model.decode_arrays(z, True, (u_type, u_edge))
+    types, adj, n_g = ga.to_dense()
+    same = [(n_g[b] == n_o[b]) and np.array_equal(types[b], t_o[b]) and np.array_equal(adj[b], a_o[b]) for b in range(B)]
+    assert sum(same) >= 0.99 * B, "%d of %d graphs differ from the oracle" % (B - sum(same), B)
+    assert len(set(n_g.tolist())) > 1  # graphs of several sizes were generated
+    # every decoded graph is a well-formed input of the train step
+    mu, logvar = model.encode(ga)
+    loss, _, _ = model.loss(mu, logvar, ga)
+    assert torch.isfinite(loss).item()
+    # default path: device RNG, DAG objects
+    gs = model.generate_sample(16)
+    assert len(gs) == 16 and all(g.is_dag() and g.vs[0]["type"] == 0 for g in gs)
+    assert len(model.encode_decode(ga[:8])) == 8

@@ -64,3 +64,17 @@ def test_oracle_matches_reference_hs501(path):
         assert abs(g.double().norm().item() - gn[0]) <= 2e-5 * gn[0] + 1e-9, k
         sl = torch.from_numpy(d["gslice::" + k])
         assert (g.reshape(-1)[:sl.numel()] - sl).abs().max() <= 2e-5 * max(1e-3, sl.abs().max().item()) + 1e-7, k
+
+
+DECODE = golden_files("decode_*")
+
+
+@pytest.mark.parametrize("path", DECODE, ids=[os.path.basename(p)[:-4] for p in DECODE])
+def test_oracle_decode_reproduces_reference_graphs(path):
+    """oracle.decode against graphs the reference itself decoded (oracle/gen_golden_decode.py:
+    same weights, same latent points, the reference's random draws replayed): exact."""
+    d, cls, ctor = load_case(path)
+    sd = state_dict_of(d)
+    types, adj, n_g = O.decode(cfg_of(cls, ctor), sd, torch.from_numpy(d["z"]), bool(int(d["stochastic"])),
+                               d["u_type"], d["u_edge"])
+    assert np.array_equal(n_g, d["n_g"]) and np.array_equal(types, d["types"]) and np.array_equal(adj, d["adj"])
