@@ -6,7 +6,7 @@ sys.modules as `dvae_amd`.
 """
 from .batching import DAGBatch, GraphArrays, graphs_to_arrays, shard_bounds  # noqa: F401
 from .models import DVAE, DVAE_BN, PARAM_NAMES  # noqa: F401
-from . import _lib, data, dist, graph, optim  # noqa: F401
+from . import _lib, data, dist, graph, harness, optim  # noqa: F401
 from .graph import DAG  # noqa: F401
 
 __all__ = ["DVAE", "DVAE_BN", "DAG", "DAGBatch", "GraphArrays", "graphs_to_arrays", "shard_bounds", "PARAM_NAMES"]

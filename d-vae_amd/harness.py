@@ -1,0 +1,172 @@
+"""Epoch-level harness around the GPU train step: the loops of the reference's experiment
+driver that call the model (`/root/reference/train.py`), as plain functions with explicit
+arguments instead of module globals and argparse state.
+
+  train_epoch        train.py:209-262   shuffle, batch, zero_grad / encode / loss / backward / step
+  test               train.py:282-330   NLL + reconstruction accuracy (encode_times x decode_times decodings)
+  extract_latent     train.py:383-404   latent means of a data set
+  prior_validity     train.py:333-380   validity / uniqueness / novelty of decodings from the prior
+  save_checkpoint    train.py:705-712   model / optimizer / scheduler state dicts per epoch
+  load_module_state  util.py:38-60      filtered (unknown keys dropped) state-dict load
+
+Data sets come in the two forms of `data.load_ENAS_graphs` / `load_BN_graphs`: a list of
+(graph, y) pairs (the reference's form) or a pre-packed (GraphArrays, y[]) pair.  Plots,
+progress bars, latent-space figures and the Bayesian-optimisation scripts are not rebuilt.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from .batching import GraphArrays, graphs_to_arrays
+from . import data as D
+
+
+def _as_arrays(dataset, max_n):
+    """(GraphArrays, y) whatever form the data set came in"""
+    if isinstance(dataset, tuple) and isinstance(dataset[0], GraphArrays):
+        return dataset[0], np.asarray(dataset[1], np.float64)
+    graphs = [g for g, _ in dataset]
+    ys = np.asarray([y for _, y in dataset], np.float64)
+    return graphs_to_arrays(graphs, max_n), ys
+
+
+def _batches(n_items, batch_size):
+    return [(lo, min(lo + batch_size, n_items)) for lo in range(0, n_items, batch_size)]
+
+
+def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predictor=False, reducer=None,
+                on_batch=None):
+    """One pass over the training set (train.py:209-262).  Returns the SUMS over the epoch of
+    (loss, recon, kld[, pred]) exactly as the reference accumulates them.  `rng` shuffles the
+    data (the reference shuffles its list in place with the global `random`); `reducer`
+    (dist.GradSumReducer) makes it data parallel: every rank passes its own shard."""
+    model.train()
+    ga, ys = _as_arrays(train_data, model.max_n)
+    order = list(range(len(ga)))
+    rng.shuffle(order)
+    dev = model.get_device()
+    tot = torch.zeros(4, dtype=torch.float64, device=dev)
+    for lo, hi in _batches(len(order), batch_size):
+        idx = order[lo:hi]
+        optimizer.zero_grad()
+        batch = model._collate_fn(ga.select(idx))
+        mu, logvar = model.encode(batch)
+        loss, recon, kld = model.loss(mu, logvar, batch)
+        pred = torch.zeros((), device=dev)
+        if predictor:
+            y = torch.as_tensor(ys[idx], dtype=torch.float32, device=dev).unsqueeze(1)
+            pred = model.mseloss(model.predictor(mu), y)
+            loss = loss + pred
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        optimizer.step()
+        tot += torch.stack([loss.detach(), recon.detach(), kld.detach(), pred.detach()]).double()  # no host sync
+        if on_batch is not None:
+            on_batch(hi, len(order))
+    t = tot.tolist()
+    return (t[0], t[1], t[2], t[3]) if predictor else (t[0], t[1], t[2])
+
+
+@torch.no_grad()
+def extract_latent(model, dataset, infer_batch_size=128):
+    """train.py:383-404: (Z [N, nz] latent means, Y [N])"""
+    model.eval()
+    ga, ys = _as_arrays(dataset, model.max_n)
+    Z = []
+    for lo, hi in _batches(len(ga), infer_batch_size):
+        mu, _ = model.encode(ga[lo:hi])
+        Z.append(mu)
+    return torch.cat(Z, 0).cpu().numpy(), ys
+
+
+def _same_graph_count(a, b):
+    """number of positions where the two GraphArrays hold the same DAG (is_same_DAG, util.py:466-476:
+    same size, same vertex types, same predecessor sets)"""
+    same = (a.n_vertices == b.n_vertices)
+    same &= (a.types == b.types).all(1)  # entries past a graph's size are 0 in both
+    same &= (a.pred_mask == b.pred_mask).all(1)
+    return int(same.sum())
+
+
+@torch.no_grad()
+def test(model, test_data, infer_batch_size=128, encode_times=10, decode_times=10, predictor=False):
+    """train.py:282-330: average NLL of the test graphs and reconstruction accuracy = fraction of
+    exact reconstructions over encode_times samples of z x decode_times stochastic decodings."""
+    model.eval()
+    ga, ys = _as_arrays(test_data, model.max_n)
+    dev = model.get_device()
+    nll_sum, pred_sum, n_perfect = 0.0, 0.0, 0
+    for lo, hi in _batches(len(ga), infer_batch_size):
+        g = ga[lo:hi]
+        batch = model._collate_fn(g)
+        mu, logvar = model.encode(batch)
+        _, nll, _ = model.loss(mu, logvar, batch)
+        nll_sum += nll.item()
+        if predictor:
+            y = torch.as_tensor(ys[lo:hi], dtype=torch.float32, device=dev).unsqueeze(1)
+            pred_sum += model.mseloss(model.predictor(mu), y).item()
+        for _ in range(encode_times):
+            z = model.reparameterize(mu, logvar)
+            for _ in range(decode_times):
+                n_perfect += _same_graph_count(g, model.decode_arrays(z))
+    n = len(ga)
+    acc = n_perfect / float(n * encode_times * decode_times)
+    if predictor:
+        return nll_sum / n, acc, (pred_sum / n) ** 0.5
+    return nll_sum / n, acc
+
+
+@torch.no_grad()
+def prior_validity(model, train_data, data_type="ENAS", n_latent_points=1000, decode_times=10, infer_batch_size=128,
+                   scale_to_train_range=False):
+    """train.py:333-380: decode points drawn from the prior; returns (valid, unique, novel) ratios."""
+    model.eval()
+    dev = model.get_device()
+    z_mean = z_std = None
+    if scale_to_train_range:
+        Z, _ = extract_latent(model, train_data, infer_batch_size)
+        z_mean = torch.as_tensor(Z.mean(0), dtype=torch.float32, device=dev)
+        z_std = torch.as_tensor(Z.std(0), dtype=torch.float32, device=dev)
+    valid_fn = D.is_valid_ENAS if data_type == "ENAS" else (lambda g, s, e: D.is_valid_BN(g, s, e, nvt=model.nvt))
+    G_valid = []
+    for lo, hi in _batches(n_latent_points, infer_batch_size):
+        z = torch.randn(hi - lo, model.nz, device=dev)
+        if scale_to_train_range:
+            z = z * z_std + z_mean
+        for _ in range(decode_times):
+            for g in model.decode(z):
+                if valid_fn(g, model.START_TYPE, model.END_TYPE):
+                    G_valid.append(g)
+    r_valid = len(G_valid) / float(n_latent_points * decode_times)
+    strs = [D.decode_igraph_to_ENAS(g) for g in G_valid]
+    r_unique = len(set(strs)) / float(len(strs)) if strs else 0.0
+    ga, _ = _as_arrays(train_data, model.max_n)
+    r_novel = 1.0 - D.ratio_same_DAG(ga.to_graphs(), G_valid)
+    return r_valid, r_unique, r_novel
+
+
+def save_checkpoint(res_dir, epoch, model, optimizer=None, scheduler=None):
+    """train.py:705-712 file names: {model,optimizer,scheduler}_checkpoint<epoch>.pth"""
+    os.makedirs(res_dir, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(res_dir, "model_checkpoint%d.pth" % epoch))
+    if optimizer is not None:
+        torch.save(optimizer.state_dict(), os.path.join(res_dir, "optimizer_checkpoint%d.pth" % epoch))
+    if scheduler is not None:
+        torch.save(scheduler.state_dict(), os.path.join(res_dir, "scheduler_checkpoint%d.pth" % epoch))
+
+
+def load_module_state(module, state_name, map_location=None):
+    """util.py:38-60: load a saved state dict, dropping keys the module does not have (for a
+    model; optimizers and schedulers load their dict whole).  Tensors only: weights_only load."""
+    state = torch.load(state_name, map_location=map_location, weights_only=True)
+    if isinstance(module, torch.nn.Module):
+        own = module.state_dict()
+        state = {k: v for k, v in state.items() if k in own}
+        module.load_state_dict(state, strict=False)
+        if hasattr(module, "_pw"):
+            module._pw = None  # weights changed: repack
+    else:
+        module.load_state_dict(state)

@@ -16,8 +16,12 @@ from .dist import GradSumReducer
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, extra_params=None):
+        """extra_params: parameters outside the hot path (e.g. the optional `model.predictor` head of
+        train.py:165-172); they are stepped by a torch.optim.Adam with the same hyper-parameters."""
         self.model = model
+        extra = [p for p in (extra_params or [])]
+        self.extra = torch.optim.Adam(extra, lr=lr, betas=betas, eps=eps) if extra else None
         self.reducer = reducer if reducer is not None else GradSumReducer(model)
         r = self.reducer
         if not r.flat.is_cuda:
@@ -36,6 +40,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero()
+        if self.extra is not None:
+            self.extra.zero_grad()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,12 +55,17 @@ class FlatAdam(torch.optim.Optimizer):
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dvae_adam_step_f32")
         # the kernel wrote through raw pointers: tensor versions did not move, so drop the packed copy
         self.model._pw = None
+        if self.extra is not None:
+            for eg in self.extra.param_groups:
+                eg["lr"] = g["lr"]  # follows a scheduler attached to this optimizer
+            self.extra.step()
         return loss
 
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "names": list(self.reducer.names), "offsets": list(self.reducer.offsets),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "extra": self.extra.state_dict() if self.extra is not None else None}
 
     def load_state_dict(self, sd):
         if list(sd["names"]) != list(self.reducer.names):
@@ -64,3 +75,5 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update(saved)
+        if self.extra is not None and sd.get("extra") is not None:
+            self.extra.load_state_dict(sd["extra"])

@@ -1,0 +1,76 @@
+"""Epoch harness on the GPU (reference train.py loops): a few epochs on a small synthetic ENAS
+set must reduce the loss; test / extract_latent / prior_validity run end to end; checkpoints
+round-trip; the optional predictor head trains alongside."""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from _dvae_pkg import dvae_amd
+from dvae_amd import data as D, harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(n=192, seed=0):
+    rows = D.synth_enas_rows(n, 6, 6, 0.3, seed)
+    ga = D.enas_rows_to_arrays(rows, 8)
+    y = np.asarray([sum(sum(r[1:]) for r in row) / 15.0 for row in rows])  # a structural target: edge density
+    return (ga, y)
+
+
+def test_epochs_reduce_loss_and_eval_paths_run(tmp_path):
+    torch.manual_seed(0)
+    train, test = _dataset(192, 0), _dataset(48, 1)
+    model = dvae_amd.DVAE(8, 8, 0, 1, hs=64, nz=16, bidirectional=True).cuda()
+    opt = dvae_amd.optim.FlatAdam(model, lr=2e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", factor=0.1, patience=10)
+    rng = random.Random(0)
+    losses = []
+    for epoch in range(1, 7):
+        tl, rl, kl = H.train_epoch(model, opt, train, batch_size=32, rng=rng)
+        assert np.isfinite(tl) and abs(tl - (rl + 0.005 * kl)) <= 1e-3 * abs(tl)
+        losses.append(tl / 192)
+        sched.step(tl)
+    assert losses[-1] < 0.8 * losses[0], losses
+    nll, acc = H.test(model, test, infer_batch_size=32, encode_times=2, decode_times=2)
+    assert np.isfinite(nll) and 0.0 <= acc <= 1.0
+    Z, Y = H.extract_latent(model, train, infer_batch_size=64)
+    assert Z.shape == (192, 16) and Y.shape == (192,) and np.isfinite(Z).all()
+    rv, ru, rn = H.prior_validity(model, train, "ENAS", n_latent_points=64, decode_times=2, infer_batch_size=32,
+                                  scale_to_train_range=True)
+    assert 0.0 <= rv <= 1.0 and 0.0 <= ru <= 1.0 and 0.0 <= rn <= 1.0
+    # checkpoint round trip (file names of train.py:705-712), into a fresh model + optimizer
+    H.save_checkpoint(str(tmp_path), 6, model, opt, sched)
+    model2 = dvae_amd.DVAE(8, 8, 0, 1, hs=64, nz=16, bidirectional=True).cuda()
+    opt2 = dvae_amd.optim.FlatAdam(model2, lr=2e-3)
+    H.load_module_state(model2, str(tmp_path / "model_checkpoint6.pth"))
+    H.load_module_state(opt2, str(tmp_path / "optimizer_checkpoint6.pth"))
+    model.eval(), model2.eval()
+    with torch.no_grad():
+        mu1, _ = model.encode(test[0])
+        mu2, _ = model2.encode(test[0])
+    assert torch.equal(mu1, mu2)
+    assert opt2.steps == opt.steps and torch.equal(opt2.exp_avg, opt.exp_avg)
+    # both continue identically
+    a = H.train_epoch(model, opt, train, 32, random.Random(5))
+    b = H.train_epoch(model2, opt2, train, 32, random.Random(5))
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0])
+
+
+def test_predictor_head_and_list_of_pairs_dataset():
+    torch.manual_seed(1)
+    ga, y = _dataset(96, 2)
+    pairs = list(zip(ga.to_graphs(), y.tolist()))  # the reference's data-set form: [(graph, y), ...]
+    model = dvae_amd.DVAE_BN(8, 8, 0, 1, hs=48, nz=8).cuda()
+    model.predictor = nn.Sequential(nn.Linear(8, 48), nn.Tanh(), nn.Linear(48, 1)).cuda()  # train.py:165-172
+    model.mseloss = nn.MSELoss(reduction="sum")
+    opt = dvae_amd.optim.FlatAdam(model, lr=2e-3, extra_params=model.predictor.parameters())
+    first = H.train_epoch(model, opt, pairs, 32, random.Random(0), predictor=True)
+    for _ in range(5):
+        last = H.train_epoch(model, opt, pairs, 32, random.Random(0), predictor=True)
+    assert len(first) == 4 and last[0] < first[0] and last[3] < first[3]
+    nll, acc, rmse = H.test(model, pairs, 32, 1, 1, predictor=True)
+    assert np.isfinite(nll) and np.isfinite(rmse)
