@@ -24,34 +24,77 @@ class GradSumReducer(object):
     def __init__(self, model, live_names=None, sink=True):
         named = dict(model.named_parameters())
         if live_names is None:
-            live_names = list(dict.fromkeys(list(model._enc_names) + list(model._dec_names)))
+            # decoder-only parameters first: their gradients are final when loss.backward() has run
+            # the decoder, so that part of the buffer is reduced while the encoder's backward is
+            # still computing (the rest, the encoder's and the shared gate/mapper, follows)
+            enc = list(model._enc_names)
+            early = [k for k in model._dec_names if k not in enc]
+            live_names = early + list(dict.fromkeys(enc + list(model._dec_names)))
+            live_names = list(dict.fromkeys(live_names))
+            n_early_names = len(early)
+        else:
+            n_early_names = 0
         self.params = [named[k] for k in live_names]
         self.names = list(live_names)
         # every slice starts on a 256-byte boundary (vector loads / stores of the optimizer kernel)
         self.offsets = []
         off = 0
-        for p in self.params:
+        self.n_early = 0
+        for i, p in enumerate(self.params):
+            if i == n_early_names:
+                self.n_early = off
             self.offsets.append(off)
             off += (p.numel() + 63) // 64 * 64
+        if n_early_names == len(self.params):
+            self.n_early = off
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=self.params[0].device)
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self._early = None
         # backward() then adds straight into these views (no autograd accumulation kernels)
         if sink and hasattr(model, "attach_grad_sink") and self.flat.is_cuda:
-            model.attach_grad_sink(True)
+            model.attach_grad_sink(True, self)
+
+    @staticmethod
+    def _collective():
+        """is there an exchange step?  (DVAE_FORCE_COLLECTIVE=1 runs it in a 1-rank group too, which
+        is how the RCCL path is exercised on a one-GPU box)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        import os
+        return dist.get_world_size() > 1 or os.environ.get("DVAE_FORCE_COLLECTIVE") == "1"
+
+    def decoder_grads_ready(self):
+        """Called by the model when loss.backward() has added the decoder's gradients: starts the
+        SUM all-reduce of the decoder-only part asynchronously (RCCL orders it after the work
+        already enqueued on the compute stream) so that it overlaps the encoder's backward."""
+        if self.n_early == 0 or self._early is not None or not self._collective():
+            return
+        if not self.flat.is_cuda or dist.get_backend() != "nccl":
+            return
+        self._early = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
 
     def zero(self):
+        if self._early is not None:  # a step was abandoned between backward() and all_reduce()
+            self._early.wait()
+            self._early = None
         self.flat.zero_()
 
     def all_reduce(self):
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not self._collective():
             return
         if self.flat.is_cuda and dist.get_backend() == "gloo":
             # rehearsal path (several ranks sharing one GPU): gloo reduces on the host
             host = self.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             self.flat.copy_(host)
+            return
+        if self._early is not None:
+            self._early.wait()  # the compute stream waits for the early part
+            self._early = None
+            if self.n_early < self.numel:
+                dist.all_reduce(self.flat[self.n_early:], op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)  # RCCL over xGMI when backend == "nccl"
 

@@ -133,6 +133,8 @@ class _LossFn(torch.autograd.Function):
                                           g3.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(), pg.data_ptr(), _stream()),
                    "dvae_loss_backward")
         grads = model._unpack(ctx.pw, pg, model._dec_names)
+        if model._grad_sink and getattr(model, "_reducer", None) is not None:
+            model._reducer.decoder_grads_ready()
         return (None, None, None, None, None, None, dmu, dlogvar) + tuple(grads)
 
 
@@ -194,6 +196,7 @@ class DVAE(nn.Module):
         self._pw_key = None
         self._named_cache = None
         self._grad_sink = getattr(self, "_grad_sink", False)
+        self._reducer = getattr(self, "_reducer", None)
         self._enc_names = _ENC_FWD + (_ENC_BWD if self.bidir else [])
         self._dec_names = list(_DEC)
         self.eps_override = None  # test hook: fixed normal draw for reparameterize
@@ -269,12 +272,13 @@ class DVAE(nn.Module):
                                          _stream()), "dvae_unpack_grads")
         return grads
 
-    def attach_grad_sink(self, on=True):
+    def attach_grad_sink(self, on=True, reducer=None):
         """Gradient sink: backward() adds the gradients of the hot-path parameters straight into
         their preallocated .grad tensors (e.g. the views of `dist.GradSumReducer`'s flat buffer)
         instead of returning them to autograd.  Same .grad contents after loss.backward(); the
         difference is only visible to torch.autograd.grad(), which then sees no gradient."""
         self._grad_sink = bool(on)
+        self._reducer = reducer if on else None  # told when the decoder's gradients are final
         return self
 
     def _as_batch(self, G):
