@@ -29,10 +29,14 @@
 
 namespace dvae {
 
-constexpr int BK = 32;
+#ifndef DVAE_GEMM_BK
+#define DVAE_GEMM_BK 32
+#endif
+constexpr int BK = DVAE_GEMM_BK;
+constexpr int C4R = BK / 4;  // float4 chunks per K-contiguous tile row
 constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
 #ifndef DVAE_GEMM_MIDG
-#define DVAE_GEMM_MIDG 1
+#define DVAE_GEMM_MIDG (DVAE_GEMM_BK / 16 - 1)
 #endif
 constexpr int MIDG = DVAE_GEMM_MIDG;  // k-group of a step after which the next tile is staged
 
@@ -59,7 +63,7 @@ struct TileLoader {
                                           int r0_, int rdim, int tid) {
         int u = tid + 256 * i;
         if (!KMAJOR) {
-            int row = u >> 3, c4 = u & 7;
+            int row = u / C4R, c4 = u % C4R;
             int r = r0_ + row;
             r = r < rdim ? r : rdim - 1;  // clamped rows are computed but never stored
             long ridx = rows ? (long)rows[r] : (long)r;
@@ -142,7 +146,7 @@ struct TileLoader {
     __device__ __forceinline__ static void store1(float* lds, int i, int tid, float4 v) {
         int u = tid + 256 * i;
         if (!KMAJOR) {
-            int row = u >> 3, c4 = u & 7;
+            int row = u / C4R, c4 = u % C4R;
             *reinterpret_cast<float4*>(lds + row * KC_LD + c4 * 4) = v;
         } else {
             int k = u / (ROWS / 4), m4 = u % (ROWS / 4);

@@ -331,3 +331,52 @@ def test_decode_random_matches_oracle_and_round_trips(cls):
     gs = model.generate_sample(16)
     assert len(gs) == 16 and all(g.is_dag() and g.vs[0]["type"] == 0 for g in gs)
     assert len(model.encode_decode(ga[:8])) == 8
+
+
+@pytest.mark.parametrize("cls", ["DVAE", "DVAE_BN"])
+def test_edge_cases_smallest_graphs_and_single_graph_batch(cls):
+    """Smallest legal graphs (START -> END only, 2 vertices) mixed with full-size ones, and a
+    batch of ONE graph: padding rules of models.py:820-823, 839-841 at their extremes."""
+    rng = np.random.default_rng(33)
+    n, T, hs, nz = 8, 8, 40, 6
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=1)
+    model = make_model(cls, ctor, 6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    types, adj, n_g = _random_batch(rng, 6, n, T, 0.4, True)
+    for b in (1, 4):  # two-vertex graphs
+        n_g[b] = 2
+        types[b] = 0
+        types[b, 1] = 1
+        adj[b] = 0
+        adj[b, 0, 1] = 1
+    n_g[0] = n
+    model.cuda()
+    for sl in (slice(0, 6), slice(1, 2), slice(0, 1)):
+        t, a, k = types[sl], adj[sl], n_g[sl]
+        eps = torch.from_numpy(rng.standard_normal((len(k), nz)).astype(np.float32))
+        r32, r64 = oracle_truth(cls, ctor, sd, t, a, k, eps)
+        loss, res, kld, mu, logvar = _run(model, dvae_amd.GraphArrays.from_dense(t, a, k), eps)
+        assert abs(loss.item() - r64[0].item()) <= TOL * abs(r64[0].item()), sl
+        assert rel_err(mu, r64[3]) < TOL and rel_err(logvar, r64[4]) < TOL
+        assert_grads_match(model, r32, r64, TOL)
+
+
+def test_malformed_inputs_are_rejected_before_launch():
+    model = make_model("DVAE", dict(max_n=6, nvt=5, START_TYPE=0, END_TYPE=1, hs=32, nz=4, bidirectional=0), 1).cuda()
+    ok_t = np.array([[0, 2, 3, 1, 0, 0]])
+    ok_a = np.zeros((1, 6, 6), np.uint8)
+    ok_a[0, 0, 1] = ok_a[0, 1, 2] = ok_a[0, 2, 3] = 1
+    model.encode(dvae_amd.GraphArrays.from_dense(ok_t, ok_a, np.array([4])))
+    bad_type = ok_t.copy()
+    bad_type[0, 1] = 7  # >= nvt
+    with pytest.raises((ValueError, dvae_amd._lib.DvaeHipError)):
+        model.encode(dvae_amd.GraphArrays.from_dense(bad_type, ok_a, np.array([4])))
+    back = ok_a.copy()
+    back[0, 3, 2] = 1  # edge against the topological order
+    with pytest.raises((ValueError, dvae_amd._lib.DvaeHipError)):
+        model.encode(dvae_amd.GraphArrays.from_dense(ok_t, back, np.array([4])))
+    with pytest.raises((ValueError, dvae_amd._lib.DvaeHipError)):
+        model.encode(dvae_amd.GraphArrays.from_dense(np.zeros((1, 9), np.int64), np.zeros((1, 9, 9), np.uint8), np.array([9])))
+    with pytest.raises(ValueError):
+        model.loss(torch.zeros(3, 4, device="cuda"), torch.zeros(3, 4, device="cuda"),
+                   dvae_amd.GraphArrays.from_dense(ok_t, ok_a, np.array([4])))
