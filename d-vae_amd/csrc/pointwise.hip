@@ -225,7 +225,17 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__
     int r1 = min(min(r0 + rows_per_chunk, (seg + 1) * seg_rows), rows);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < w4) {
-        for (int r = r0 + ty; r < r1; r += 4) acc = add4(acc, ld4(x + (long)r * ld_x + c4 * 4));
+        // four independent row streams per thread keep 4 loads in flight (the loop is latency bound)
+        const float* base = x + c4 * 4;
+        float4 a1 = acc, a2 = acc, a3 = acc;
+        int r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
+            float4 v0 = ld4(base + (long)r * ld_x), v1 = ld4(base + (long)(r + 4) * ld_x);
+            float4 v2 = ld4(base + (long)(r + 8) * ld_x), v3 = ld4(base + (long)(r + 12) * ld_x);
+            acc = add4(acc, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
+        }
+        for (; r < r1; r += 4) acc = add4(acc, ld4(base + (long)r * ld_x));
+        acc = add4(add4(acc, a1), add4(a2, a3));
     }
     red[ty][tx] = acc;
     __syncthreads();
