@@ -36,8 +36,46 @@ def _batches(n_items, batch_size):
     return [(lo, min(lo + batch_size, n_items)) for lo in range(0, n_items, batch_size)]
 
 
+def _packed_batches(model, ga, order, batch_size, prefetch):
+    """Yields (indices, packed DAGBatch).  With prefetch the next batches are packed (C++ packer,
+    which releases the GIL, + the H2D copy of the index blob) by a background thread while the GPU
+    works on the current one."""
+    spans = _batches(len(order), batch_size)
+    if not prefetch or len(spans) < 2:
+        for lo, hi in spans:
+            idx = order[lo:hi]
+            yield idx, model._collate_fn(ga.select(idx))
+        return
+    import queue
+    import threading
+    q = queue.Queue(maxsize=3)
+    dev = model.get_device()
+
+    def work():
+        try:
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            for lo, hi in spans:
+                idx = order[lo:hi]
+                q.put((idx, model._collate_fn(ga.select(idx))))
+            q.put(None)
+        except BaseException as e:  # surfaces in the consumer
+            q.put(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        item = q.get()
+        if item is None:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+    t.join()
+
+
 def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predictor=False, reducer=None,
-                on_batch=None):
+                on_batch=None, prefetch=True):
     """One pass over the training set (train.py:209-262).  Returns the SUMS over the epoch of
     (loss, recon, kld[, pred]) exactly as the reference accumulates them.  `rng` shuffles the
     data (the reference shuffles its list in place with the global `random`); `reducer`
@@ -48,10 +86,9 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
     rng.shuffle(order)
     dev = model.get_device()
     tot = torch.zeros(4, dtype=torch.float64, device=dev)
-    for lo, hi in _batches(len(order), batch_size):
-        idx = order[lo:hi]
+    done = 0
+    for idx, batch in _packed_batches(model, ga, order, batch_size, prefetch):
         optimizer.zero_grad()
-        batch = model._collate_fn(ga.select(idx))
         mu, logvar = model.encode(batch)
         loss, recon, kld = model.loss(mu, logvar, batch)
         pred = torch.zeros((), device=dev)
@@ -64,8 +101,9 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
             reducer.all_reduce()
         optimizer.step()
         tot += torch.stack([loss.detach(), recon.detach(), kld.detach(), pred.detach()]).double()  # no host sync
+        done += len(idx)
         if on_batch is not None:
-            on_batch(hi, len(order))
+            on_batch(done, len(order))
     t = tot.tolist()
     return (t[0], t[1], t[2], t[3]) if predictor else (t[0], t[1], t[2])
 
