@@ -47,6 +47,14 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
+        r = self.reducer
+        for p, o in zip(r.params, r.offsets):
+            # .to() / .cuda() / .float() on the model re-allocate parameters: the views would be gone
+            if p.data_ptr() != self.flat_p.data_ptr() + 4 * o or p.grad is None or \
+                    p.grad.data_ptr() != r.flat.data_ptr() + 4 * o:
+                raise _lib.DvaeHipError("FlatAdam: a parameter (or its .grad) no longer lives in the flat buffers "
+                                        "(was the model moved or its gradients set to None after the optimizer "
+                                        "was built?); build the optimizer after the last .to()")
         self.steps += 1
         lib = _lib.load()
         _lib.check(lib.dvae_adam_step_f32(self.flat_p.data_ptr(), self.reducer.flat.data_ptr(), self.exp_avg.data_ptr(),

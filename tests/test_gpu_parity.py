@@ -380,3 +380,13 @@ def test_malformed_inputs_are_rejected_before_launch():
     with pytest.raises(ValueError):
         model.loss(torch.zeros(3, 4, device="cuda"), torch.zeros(3, 4, device="cuda"),
                    dvae_amd.GraphArrays.from_dense(ok_t, ok_a, np.array([4])))
+
+
+def test_flat_adam_detects_moved_parameters():
+    ctor = dict(max_n=8, nvt=8, START_TYPE=0, END_TYPE=1, hs=32, nz=4, bidirectional=0)
+    model = make_model("DVAE", ctor, 2).cuda()
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-3)
+    opt.step()  # fine: zero gradients
+    model.zero_grad(set_to_none=True)  # the views are gone
+    with pytest.raises(dvae_amd._lib.DvaeHipError, match="flat buffers"):
+        opt.step()
