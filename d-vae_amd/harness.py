@@ -124,8 +124,9 @@ def _same_graph_count(a, b):
     """number of positions where the two GraphArrays hold the same DAG (is_same_DAG, util.py:466-476:
     same size, same vertex types, same predecessor sets)"""
     same = (a.n_vertices == b.n_vertices)
-    same &= (a.types == b.types).all(1)  # entries past a graph's size are 0 in both
-    same &= (a.pred_mask == b.pred_mask).all(1)
+    live = np.arange(a.max_n)[None, :] < a.n_vertices[:, None]  # entries past a graph's size carry no meaning
+    same &= ((a.types == b.types) | ~live).all(1)
+    same &= ((a.pred_mask == b.pred_mask) | ~live).all(1)
     return int(same.sum())
 
 
