@@ -187,14 +187,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int m0, n0;
-    tile_origin<BM, BN>(m0, n0);
     int kbeg = 0, kend = p.K;
     if (p.split_k > 1) {
         kbeg = blockIdx.z * p.k_per_split;
         kend = min(p.K, kbeg + p.k_per_split);
         if (kbeg >= kend) return;
     }
+    // Persistent over output tiles: the launch has at most as many workgroups as fit on the chip
+    // at once; each walks its tiles, so a tile's stores drain under the next tile's prologue
+    // instead of holding the workgroup's slot until they are acknowledged.
+    const int ntiles = p.tiles_x * p.tiles_y;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    int m0, n0;
+    tile_origin<BM, BN>(tl, p.tiles_x, ntiles, m0, n0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -263,11 +268,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 
     store_acc<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+    }  // tiles
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmParams& p, int akm, int bkm, hipStream_t s) {
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.split_k > 1 ? p.split_k : 1);
+static int launch_cfg(GemmParams p, int akm, int bkm, hipStream_t s) {
+    p.tiles_x = cdiv(p.N, BN);
+    p.tiles_y = cdiv(p.M, BM);
+    const long ntiles = (long)p.tiles_x * p.tiles_y;
+    const long cap = (BM * BN >= 128 * 128 ? 512 : 1024);  // co-resident workgroups the chip holds (multiple of 8: XCD runs)
+    dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, p.split_k > 1 ? p.split_k : 1);
     dim3 block(256);
     const bool kg = bkm && p.b_rows != nullptr;
     if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");

@@ -20,15 +20,14 @@ struct GemmParams {
     int accumulate;  // C += result
     int split_k;     // >1: atomicAdd into C (C must hold the running sum / zeros)
     int k_per_split; // multiple of the kernel's K step
+    int tiles_x, tiles_y;  // output tiles along N and M; workgroup w walks tiles w, w + gridDim.x, ...
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
 // L2), so workgroup ids that are equal mod 8 share an L2.  Give each such group a contiguous
 // run of tiles (N fastest), so the tiles that re-read one A row block meet in one L2.
 template <int BM, int BN>
-__device__ __forceinline__ void tile_origin(int& m0, int& n0) {
-    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int orig = blockIdx.y * nx + blockIdx.x;
+__device__ __forceinline__ void tile_origin(int orig, int nx, int nwg, int& m0, int& n0) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     m0 = (id / nx) * BM;
