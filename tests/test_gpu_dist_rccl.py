@@ -18,7 +18,11 @@ pytestmark = pytest.mark.gpu
 
 def test_rccl_one_rank_exchange_is_identity_and_overlapped_part_is_launched():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29533"
+    import socket
+    with socket.socket() as sk:  # a free port: nothing else may be listening on a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_PORT"] = str(port)
     os.environ["DVAE_FORCE_COLLECTIVE"] = "1"
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:

@@ -390,3 +390,29 @@ def test_flat_adam_detects_moved_parameters():
     model.zero_grad(set_to_none=True)  # the views are gone
     with pytest.raises(dvae_amd._lib.DvaeHipError, match="flat buffers"):
         opt.step()
+
+
+def test_decode_max_size_n64_and_novid_match_oracle():
+    """generation at max_n = 64 (all 64 mask bits in play) and without vertex-id features"""
+    rng = np.random.default_rng(8)
+    for n, vid, B in ((64, 1, 12), (9, 0, 60)):
+        T, hs, nz = 6, 32, 6
+        ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=0, vid=vid)
+        model = make_model("DVAE", ctor, 7)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if k.startswith(("add_vertex", "add_edge", "fc3")):
+                    p.mul_(3.0)
+            model.add_vertex[2].bias[1] -= 3.0  # END rarely: long graphs
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        z = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+        u_type = rng.random((B, n)).astype(np.float32)
+        u_edge = rng.random((B, n, n)).astype(np.float32)
+        t_o, a_o, n_o = O.decode(cfg_of("DVAE", ctor), sd, z, True, u_type, u_edge)
+        model.cuda().eval()
+        types, adj, n_g = model.decode_arrays(z, True, (u_type, u_edge)).to_dense()
+        same = sum(int(n_g[b] == n_o[b] and np.array_equal(types[b], t_o[b]) and np.array_equal(adj[b], a_o[b]))
+                   for b in range(B))
+        assert same >= B - 1, "%d of %d graphs differ (n=%d)" % (B - same, B, n)
+        if n == 64:
+            assert n_g.max() > 32  # graphs beyond 32 vertices were really grown
