@@ -143,3 +143,26 @@ def shard_bounds(n_items, world_size, rank):
     chunk = -(-n_items // world_size)
     lo = min(rank * chunk, n_items)
     return lo, min(lo + chunk, n_items)
+
+
+def balanced_shard_bounds(n_vertices, world_size, rank):
+    """Contiguous split of a variable-size batch over ranks that evens out the decoder's work instead
+    of the graph count: a graph of n vertices costs n(n-1)/2 teacher-forced pairs (models.py:828-857),
+    so the cut points are where the running sum of n_g^2 crosses k/world_size of the total.  Same
+    contract as shard_bounds (contiguous, ordered, covers the batch exactly once), so the global
+    eps rows [lo, hi) still belong to rank `rank`; for equal-size graphs it is the even split."""
+    w = np.asarray(n_vertices, np.float64) ** 2
+    n_items = int(w.shape[0])
+    if n_items == 0:
+        return 0, 0
+    csum = np.cumsum(w)
+    cuts = [0]
+    for k in range(1, world_size):
+        # first index whose prefix reaches k/world of the total, never before the previous cut
+        c = int(np.searchsorted(csum, csum[-1] * k / world_size, side="left")) + 1
+        # put the boundary graph on the lighter side
+        if c - 1 > cuts[-1] and abs(csum[c - 2] - csum[-1] * k / world_size) <= abs(csum[c - 1] - csum[-1] * k / world_size):
+            c -= 1
+        cuts.append(min(max(c, cuts[-1]), n_items))
+    cuts.append(n_items)
+    return cuts[rank], cuts[rank + 1]

@@ -11,7 +11,7 @@ reduce-adds gradients onto device 0.  The loss is a SUM over graphs
 import torch
 import torch.distributed as dist
 
-from .batching import shard_bounds
+from .batching import shard_bounds, balanced_shard_bounds
 
 
 class GradSumReducer(object):
@@ -98,15 +98,34 @@ class GradSumReducer(object):
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)  # RCCL over xGMI when backend == "nccl"
 
+    def reduce_scalars(self, *values):
+        """SUM over ranks of a few scalars in one small all-reduce: the (loss, recon, kld) of a step
+        or an epoch, for logging only (every rank's loss is the sum over its own graphs).  Returns
+        a float64 tensor on the values' device; a no-op copy without a process group."""
+        t = torch.stack([torch.as_tensor(v).detach().double().reshape(()) for v in values])
+        if self._collective():
+            if t.is_cuda and dist.get_backend() == "gloo":
+                host = t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                t = host.to(t.device)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
     def nbytes(self):
         return self.flat.numel() * 4
 
 
-def shard(items, rank=None, world_size=None):
-    """This rank's contiguous ceil-split chunk of `items` (list or GraphArrays)."""
+def shard(items, rank=None, world_size=None, balance=False):
+    """This rank's contiguous chunk of `items` (list or GraphArrays): the reference's ceil-split by
+    graph count, or with balance=True (GraphArrays of variable-size graphs) the split that evens
+    out the sum of n_g^2 per rank."""
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
-    lo, hi = shard_bounds(len(items), world_size, rank)
+    if balance:
+        lo, hi = balanced_shard_bounds(items.n_vertices, world_size, rank)
+    else:
+        lo, hi = shard_bounds(len(items), world_size, rank)
     return items[lo:hi]

@@ -79,7 +79,8 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
     """One pass over the training set (train.py:209-262).  Returns the SUMS over the epoch of
     (loss, recon, kld[, pred]) exactly as the reference accumulates them.  `rng` shuffles the
     data (the reference shuffles its list in place with the global `random`); `reducer`
-    (dist.GradSumReducer) makes it data parallel: every rank passes its own shard."""
+    (dist.GradSumReducer) makes it data parallel: every rank passes its own shard and gets the
+    whole-job sums back."""
     model.train()
     ga, ys = _as_arrays(train_data, model.max_n)
     order = list(range(len(ga)))
@@ -104,6 +105,8 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
         done += len(idx)
         if on_batch is not None:
             on_batch(done, len(order))
+    if reducer is not None:
+        tot = reducer.reduce_scalars(*tot.unbind(0))  # whole-job sums on every rank: one 4-float all-reduce per epoch
     t = tot.tolist()
     return (t[0], t[1], t[2], t[3]) if predictor else (t[0], t[1], t[2])
 

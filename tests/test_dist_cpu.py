@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, path, out):
+def _worker(rank, world, port, path, out, balance):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,8 +36,11 @@ def _worker(rank, world, port, path, out):
     model.load_state_dict(state_dict_of(d))
     reducer = dvae_amd.dist.GradSumReducer(model)
     ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
-    lo, hi = dvae_amd.shard_bounds(len(ga), world, rank)
-    mine = dvae_amd.dist.shard(ga)
+    if balance:   # cut by the running sum of n_g^2 instead of the graph count
+        lo, hi = dvae_amd.balanced_shard_bounds(ga.n_vertices, world, rank)
+    else:
+        lo, hi = dvae_amd.shard_bounds(len(ga), world, rank)
+    mine = dvae_amd.dist.shard(ga, balance=balance)
     assert len(mine) == hi - lo
     types, adj, n_g = (torch.from_numpy(x) for x in mine.to_dense())
     eps = torch.from_numpy(d["eps"])[lo:hi]  # rank r uses its rows of the global normal draw
@@ -51,19 +54,18 @@ def _worker(rank, world, port, path, out):
         else:
             named[k].grad += g                        # what autograd's accumulation does after backward()
     reducer.all_reduce()
-    loss = L.clone()
-    dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+    loss = reducer.reduce_scalars(L)[0].float()       # the logging all-reduce
     if rank == 0:
         torch.save({"loss": loss, "grads": {k: (p.grad.clone() if p.grad is not None else None)
                                             for k, p in model.named_parameters()}}, out)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["dvae_tiny_bi_var", "bn_tiny_uni_full"])
-def test_two_rank_sum_allreduce_equals_single_rank(tmp_path, name):
+@pytest.mark.parametrize("name,balance", [("dvae_tiny_bi_var", False), ("dvae_tiny_bi_var", True), ("bn_tiny_uni_full", False)])
+def test_two_rank_sum_allreduce_equals_single_rank(tmp_path, name, balance):
     path = golden_files(name)[0]
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), path, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), path, out, balance), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
     d, cls, ctor = load_case(path)
     assert abs(got["loss"].item() - d["loss3"][0]) <= 1e-5 * abs(d["loss3"][0])

@@ -118,3 +118,25 @@ def test_shard_bounds_is_ceil_split():
     assert [dvae_amd.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [dvae_amd.shard_bounds(8, 2, r) for r in range(2)] == [(0, 4), (4, 8)]
     assert dvae_amd.shard_bounds(2, 4, 3) == (2, 2)
+
+
+def test_balanced_shard_bounds_partitions_and_evens_out_pair_work():
+    rng = np.random.RandomState(3)
+    for world in (1, 2, 4, 8):
+        for n_items in (0, 1, 5, 64, 1000):
+            nv = rng.randint(3, 65, size=n_items)
+            spans = [dvae_amd.balanced_shard_bounds(nv, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n_items
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))       # contiguous, ordered, no overlap
+            assert all(lo <= hi for lo, hi in spans)
+    # equal sizes: the even split, i.e. the reference's rule
+    assert [dvae_amd.balanced_shard_bounds([8] * 8, 2, r) for r in range(2)] == [(0, 4), (4, 8)]
+    # skewed batch: small graphs first, large last; the heaviest rank's share of sum n^2 drops vs the ceil split
+    nv = np.concatenate([np.full(96, 6), np.full(32, 60)])
+    w = nv.astype(np.float64) ** 2
+
+    def worst(bounds):
+        return max(w[lo:hi].sum() for lo, hi in bounds) / (w.sum() / 4)
+    ceil = worst([dvae_amd.shard_bounds(len(nv), 4, r) for r in range(4)])
+    bal = worst([dvae_amd.balanced_shard_bounds(nv, 4, r) for r in range(4)])
+    assert bal < 1.1 < ceil
