@@ -24,7 +24,10 @@
 // Both operands present the same k to the same (lane half, MFMA) so the k
 // permutation inside a group is consistent.  Global->LDS is register staged
 // (next tile's loads in flight during the current tile's MFMAs), two LDS
-// buffers, one barrier per K step.
+// buffers, one barrier per K step.  The K step is software pipelined by hand
+// (scheduling fences pin the order): fragments are read one 8-k group ahead of
+// their MFMAs, and the staging (16-byte unit: registers -> LDS, reload from
+// tile k+2) is spread one unit per MFMA quad instead of in one burst.
 #include "gemm_common.h"
 
 namespace dvae {
@@ -35,10 +38,6 @@ namespace dvae {
 constexpr int BK = DVAE_GEMM_BK;
 constexpr int C4R = BK / 4;  // float4 chunks per K-contiguous tile row
 constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
-#ifndef DVAE_GEMM_MIDG
-#define DVAE_GEMM_MIDG (DVAE_GEMM_BK / 16 - 1)
-#endif
-constexpr int MIDG = DVAE_GEMM_MIDG;  // k-group of a step after which the next tile is staged
 
 // Register-staged tile loader.  Everything that does not depend on the K step
 // (row gather, row clamping, column guards) is resolved ONCE in init(); the K loop
@@ -147,10 +146,33 @@ struct TileLoader {
         int u = tid + 256 * i;
         if (!KMAJOR) {
             int row = u / C4R, c4 = u % C4R;
-            *reinterpret_cast<float4*>(lds + row * KC_LD + c4 * 4) = v;
+            // (the hint makes this one ds_write_b128; hipcc cannot prove the alignment and emits two b64)
+            *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + row * KC_LD + c4 * 4, 16)) = v;
         } else {
             int k = u / (ROWS / 4), m4 = u % (ROWS / 4);
-            *reinterpret_cast<float4*>(lds + k * ROWS + m4 * 4) = v;
+            *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + k * ROWS + m4 * 4, 16)) = v;
+        }
+    }
+    // unit i alone: registers -> LDS image, then the same registers are reloaded from tile k0
+    // (i is a constant after unrolling; a switch over named registers keeps them out of scratch)
+    __device__ __forceinline__ void restage(int i, float* lds, int k0, int kend, int tid) {
+        switch (i) {
+        case 0:
+            store1(lds, 0, tid, r0);
+            r0 = KMAJOR ? kload(0, k0, kend, tid, c0, col0_, n0_) : *reinterpret_cast<const float4*>(p0 + k0);
+            break;
+        case 1:
+            store1(lds, 1, tid, r1);
+            r1 = KMAJOR ? kload(1, k0, kend, tid, c1, col1_, n1_) : *reinterpret_cast<const float4*>(p1 + k0);
+            break;
+        case 2:
+            store1(lds, 2, tid, r2);
+            r2 = KMAJOR ? kload(2, k0, kend, tid, c2, col2_, n2_) : *reinterpret_cast<const float4*>(p2 + k0);
+            break;
+        default:
+            store1(lds, 3, tid, r3);
+            r3 = KMAJOR ? kload(3, k0, kend, tid, c3, col3_, n3_) : *reinterpret_cast<const float4*>(p3 + k0);
+            break;
         }
     }
     __device__ __forceinline__ void store(float* lds, int tid) {
@@ -176,7 +198,7 @@ __device__ __forceinline__ float4 frag(const float* lds, int roff, int g, int la
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves");
@@ -225,49 +247,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     lb.next_idx(tile(2), kend, tid);
     __syncthreads();
 
-    // Steady state of step k: MFMAs on LDS[cur] (tile k) | registers hold tile k+1, in flight
-    // since the END of step k-1 | after the MFMAs: registers -> LDS[cur^1], then the loads of
-    // tile k+2 are issued.  Issuing at the block end keeps the loads a whole step ahead of
-    // their consumer (hipcc sinks loads placed at the top of the step down to the LDS stores;
-    // a scheduling fence there demotes the staging registers to scratch).
+    // Steady state of step t (tile t in LDS[cur], tile t+1 in the staging registers, in flight
+    // for a whole step), groups g = 0..NG-1 of 8 k each:
+    //   * the fragments of group g+1 are read while the MFMAs of group g run; the last group reads
+    //     group 0 of LDS[cur^1], i.e. of the next step;
+    //   * after each MFMA quad of groups 0..NG-2 one staging unit goes registers -> LDS[cur^1] and
+    //     is reloaded from tile t+2 (a burst of 16 LDS stores + 8 loads here cost 10 % of the MFMA
+    //     rate at 4096^3; hipcc re-clusters them unless fenced);
+    //   * ONE barrier, before the last group: by then every wave holds its last fragments of
+    //     LDS[cur] in registers (so step t+1 may overwrite it) and LDS[cur^1] is complete.
+    constexpr int NG = BK / 8;
+    constexpr int NU = LA::UNITS + LB::UNITS;
+    constexpr int SLOTS = (NG - 1) * TM * TN;
+    constexpr int UPS = (NU + SLOTS - 1) / SLOTS;  // staging units per slot
+    static_assert(NG % 2 == 0, "fragment double buffer assumes an even number of groups per step");
+    float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = frag<BM, AKM>(lds, (wm * TM + i) * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = frag<BN, BKM>(lds + LA::LDS_ELEMS, (wn * TN + j) * 32, 0, lane);
     int cur = 0, t = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK, ++t) {
-        const float* a_l = lds + cur * STAGE;
-        const float* b_l = a_l + LA::LDS_ELEMS;
+        float* nl = lds + (cur ^ 1) * STAGE;
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float4 af[TM], bf[TN];
+        for (int g = 0; g < NG; ++g) {
+            const float* src = (g < NG - 1) ? lds + cur * STAGE : nl;
+            const int gn = (g + 1) % NG;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = frag<BM, AKM>(a_l, (wm * TM + i) * 32, g, lane);
+            for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = frag<BM, AKM>(src, (wm * TM + i) * 32, gn, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = frag<BN, BKM>(b_l, (wn * TN + j) * 32, g, lane);
+            for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = frag<BN, BKM>(src + LA::LDS_ELEMS, (wn * TN + j) * 32, gn, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    // SWAP: the block is accumulated transposed (same products, same k order), which
+                    // gives each lane 4 consecutive columns of one row for the epilogue
+                    const float4 a4 = SWAP ? fb[g & 1][j] : fa[g & 1][i], b4 = SWAP ? fa[g & 1][i] : fb[g & 1][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[i][j], 0, 0, 0);
+                    if (g < NG - 1) {
+                        const int slot = (g * TM + i) * TN + j;
+#pragma unroll
+                        for (int q = 0; q < UPS; ++q) {
+                            const int u = slot * UPS + q;
+                            if (u < NU) {
+                                if (u < LA::UNITS) la.restage(u, nl, tile(t + 2), kend, tid);
+                                else lb.restage(u - LA::UNITS, nl + LA::LDS_ELEMS, tile(t + 2), kend, tid);
+                                if (u == NU - 1) lb.next_idx(tile(t + 3), kend, tid);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            if (g == MIDG) {
-                // mid-step: registers (tile k+1, in flight since the middle of step k-1) -> LDS[cur^1],
-                // then the loads of tile k+2 are issued: a whole step of MFMAs hides their latency.
-                la.store(lds + (cur ^ 1) * STAGE, tid);
-                lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
-                // fence: the loads below must not be hoisted above the LDS stores that read the same
-                // staging registers (hipcc then renames them and waits vmcnt(0) on copies at the block end)
-                __builtin_amdgcn_sched_barrier(0);
-                la.load(tile(t + 2), kend, tid);
-                lb.load(tile(t + 2), kend, tid);
-                lb.next_idx(tile(t + 3), kend, tid);
-            }
+            if (g == NG - 2) __syncthreads();
         }
-        __syncthreads();
         cur ^= 1;
     }
 
-    store_acc<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+    store_acc<TM, TN, SWAP>(p, acc, m0, n0, wm, wn, lane, BM, BN);
     }  // tiles
 }
 
@@ -281,11 +322,18 @@ static int launch_cfg(GemmParams p, int akm, int bkm, hipStream_t s) {
     dim3 block(256);
     const bool kg = bkm && p.b_rows != nullptr;
     if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, p);
-    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, p);
-    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, false>), grid, block, 0, s, p);
-    else if (akm && bkm && kg) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, true>), grid, block, 0, s, p);
+#define DVAE_GEMM_LAUNCH(A_, B_, G_)                                                                             \
+    do {                                                                                                         \
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, true>), grid, block, 0, s, p);  \
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, false>), grid, block, 0, s, p);     \
+    } while (0)
+    const bool vec = gemm_vec_epilogue_ok(p);
+    if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
+    else if (!akm && bkm && !kg) DVAE_GEMM_LAUNCH(false, true, false);
+    else if (akm && bkm && !kg) DVAE_GEMM_LAUNCH(true, true, false);
+    else if (akm && bkm && kg) DVAE_GEMM_LAUNCH(true, true, true);
     else return set_err(DVAE_ERR_ARG, "gemm: this operand layout / gather combination is not built");
+#undef DVAE_GEMM_LAUNCH
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -337,8 +385,21 @@ bool gemm_next_chunk(const dvae_gemm_desc& d, int kc, int& k0, dvae_gemm_desc& s
     return true;
 }
 
+// tuning / tracing knobs (tools/gemm_tune.py): DVAE_GEMM_LOG=1 prints every product's shape to
+// stderr, DVAE_GEMM_TILE={128,64,32} and DVAE_GEMM_SPLIT=n override the tile and split-K choice
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
 int gemm(const dvae_gemm_desc& d, hipStream_t s) {
+    static const int knob_log = env_int("DVAE_GEMM_LOG"), knob_tile = env_int("DVAE_GEMM_TILE"),
+                     knob_split = env_int("DVAE_GEMM_SPLIT");
     DVAE_TRY(gemm_check(d, 32));
+    if (knob_log)
+        fprintf(stderr, "GEMM %d %d %d akm=%d bkm=%d acc=%d bias=%d act=%d ar=%d br=%d cr=%d\n", d.M, d.N, d.K, d.a_kmajor,
+                d.b_kmajor, d.accumulate, d.bias != nullptr, d.act, d.a_rows != nullptr, d.b_rows != nullptr,
+                d.c_rows != nullptr);
     if (d.M == 0 || d.N == 0) return DVAE_OK;
     {
         const int kc = gemm_k_chunk(d, BK);
@@ -360,44 +421,62 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     if (d.K == 0) {
         // empty contraction: result is bias/act only; run with kend == 0
     }
-    // Tile and split-K choice.  The chip has 256 CUs x 4 SIMDs; a 128x128 tile keeps 4 waves
-    // busy for K/32 steps of 64 MFMAs, a 64x64 tile for K/32 steps of 16 MFMAs.  Products that
-    // accumulate into C (every dgrad / wgrad of the step) may split K across workgroups and
-    // combine with fp32 atomics; the split is chosen to put >= ~2 workgroups on every CU
-    // while keeping >= 4 K steps per workgroup.
+    // Tile and split-K choice: a small cost model fitted to sweeps of every product of the train
+    // step under forced tiles / splits on MI355X (tools/gemm_tune.py; cfg 2 and cfg 5 shapes).
+    // Unit = one K step of a 64x64 tile (16 MFMAs per wave, 0.43 us).
+    //   * run time advances in ROUNDS of 256 workgroups (one per CU; co-resident workgroups share
+    //     the MFMA pipe), so cost = rounds x (K steps per workgroup x step cost + epilogue);
+    //   * a 128x128 step costs 4 units, a 64x64 step 1.2 (half the operand reuse: more L2 traffic);
+    //     a tile kind running with fewer co-resident workgroups than hide its latencies is slower;
+    //   * epilogue + prologue: 16-byte stores 1.5 / 6 units (64 / 128 tile), split-K atomics 3 / 38.
+    // Products that accumulate into C with no bias / activation (every dgrad / wgrad of the step)
+    // may split K over workgroups that combine with fp32 atomics.
     long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     long t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
-    bool use128 = t128 >= 192 || (d.a_kmajor && t128 >= 24);
     int ksteps = cdiv(d.K, BK);
-    const bool small_m = d.M <= 32 && d.a_kmajor;
-    if (d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 8) {
-        // Split choice, fitted to measurements on MI355X (tools/gemm_quant.py, tools/gemm_bench.py):
-        // run time advances in whole ROUNDS of 256 workgroups (a launch of 528 costs as much as one
-        // of 768).  128x128 tiles: two workgroups per CU hide each other's load latency, so fill
-        // 512 slots without overshooting; with more than one round of tiles already, pick the split
-        // that minimises rounds x (K steps + ~5 steps of prologue and atomic epilogue).  64x64 tiles
-        // (four fit on a CU): three per CU.
-        const long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
-        const int maxsplit = ksteps / 4;
-        int best = 1;
-        if (use128 && !small_m && tiles <= 256) {
-            best = (int)(512 / tiles);
-        } else if (use128 && !small_m) {
-            long best_cost = -1;
-            for (int sk = 1; sk <= 16; ++sk) {
-                const long rounds = (tiles * sk + 255) / 256;
-                const long cost = rounds * (cdiv(ksteps, sk) + 5);
-                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sk; }
+    bool small_m = d.M <= 32 && d.a_kmajor;
+    const bool may_split = d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 8;
+    bool use128 = false;
+    int best = 1;
+    {
+        double best_cost = -1.0;
+        const int maxsplit = may_split ? (ksteps / 4 < 16 ? ksteps / 4 : 16) : 1;
+        for (int big = 0; big < 2; ++big) {
+            const long tiles = big ? t128 : t64;
+            for (int sk = 1; sk <= maxsplit; ++sk) {
+                const long wgs = tiles * sk;
+                const long rounds = (wgs + 255) / 256;
+                const double occ = (double)wgs / 256.0;
+                const double steps = (double)cdiv(ksteps, sk);
+                double step_cost, epi;
+                if (big) {
+                    step_cost = 4.0 * (occ < 1.5 ? 1.12 : 1.0);
+                    epi = sk > 1 ? 38.0 : 6.0;
+                } else {
+                    step_cost = 1.2 * (occ < 1.5 ? 1.3 : (occ < 2.5 ? 1.1 : 1.0));
+                    epi = sk > 1 ? 3.0 : 1.5;
+                }
+                const double cost = (double)rounds * (steps * step_cost + epi);
+                if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = sk; use128 = big != 0; }
             }
-        } else {
-            best = (int)((768 + tiles - 1) / tiles);
         }
-        if (best > maxsplit) best = maxsplit;
-        if (best < 1) best = 1;
-        if (best > 1) {
-            p.k_per_split = cdiv(ksteps, best) * BK;
-            p.split_k = cdiv(d.K, p.k_per_split);
-        }
+    }
+    if (knob_tile == 128) { use128 = true; small_m = false; }
+    else if (knob_tile == 64) { use128 = false; small_m = false; }
+    else if (knob_tile == 32) small_m = true;
+    if (small_m && may_split) {
+        // one row block (M <= 32), 32x128 tiles: three workgroups per CU
+        const long tiles = (long)cdiv(d.N, 128) * cdiv(d.M, 32);
+        best = (int)((768 + tiles - 1) / tiles);
+        if (best > ksteps / 4) best = ksteps / 4;
+    } else if (small_m) {
+        best = 1;
+    }
+    if (knob_split > 0 && may_split) best = knob_split < ksteps ? knob_split : ksteps;
+    if (best < 1) best = 1;
+    if (best > 1) {
+        p.k_per_split = cdiv(ksteps, best) * BK;
+        p.split_k = cdiv(d.K, p.k_per_split);
     }
     if (small_m) return launch_cfg<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
     if (use128) return launch_cfg<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);

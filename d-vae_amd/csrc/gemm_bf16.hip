@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             cur ^= 1;
         }
     }
-    store_acc<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+    store_acc<TM, TN, false>(p, acc, m0, n0, wm, wn, lane, BM, BN);
     }  // tiles
 }
 

@@ -34,37 +34,94 @@ __device__ __forceinline__ void tile_origin(int orig, int nx, int nwg, int& m0, 
     n0 = (id % nx) * BN;
 }
 
-// epilogue: D[row][col], col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-template <int TM, int TN>
+// Epilogue.  The MFMA leaves D[i][j] with j = lane & 31 and i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//   SWAP == false: the MFMA ran as (A, B): i is the row of C, j the column.  One instruction of
+//     a wave then covers 2 rows x 128 contiguous bytes: the form split-K uses, because the only
+//     fp32 atomic is one dword per lane.
+//   SWAP == true: the MFMA ran as (B, A), so D is the transposed block: j (the lane) is the ROW of
+//     C and a register quad holds 4 CONSECUTIVE columns: every lane loads / stores 16 bytes
+//     (4x fewer memory instructions; a row's 128-byte line is completed by 4 instructions).
+//     Needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C (and bias): the launcher checks.
+// All mode tests are wave-uniform and hoisted; an interior tile runs with no bounds checks.
+template <int TM, int TN, bool SWAP>
 __device__ __forceinline__ void store_acc(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                          int lane) {
+                                          int lane, int BM, int BN) {
     const int h = lane >> 5, cl = lane & 31;
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+    if (!SWAP) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int col = n0 + (wn * TN + j) * 32 + cl;
-        if (col >= p.N) continue;
-        float bv = p.bias ? p.bias[col] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + cl;
+            const bool colok = interior || col < p.N;
+            const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = m0 + (wm * TM + i) * 32 + 4 * h;
+                if (p.split_k > 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (interior || (colok && row < p.M)) {
+                            const long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
+                            atomicAdd(p.C + crow * p.ldc + col, acc[i][j][r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (interior || (colok && row < p.M)) {
+                            const long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
+                            float* dst = p.C + crow * p.ldc + col;
+                            float v = acc[i][j][r] + bv;
+                            if (p.act == 1) v = fmaxf(v, 0.f);
+                            else if (p.act == 2) v = tanhf(v);
+                            if (p.accumulate) v += *dst;
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int row = m0 + (wm * TM + i) * 32 + cl;
+            if (!(interior || row < p.M)) continue;
+            const long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
+            float* drow = p.C + crow * p.ldc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
-                float* dst = p.C + crow * p.ldc + col;
-                float v = acc[i][j][r];
-                if (p.split_k > 1) {
-                    atomicAdd(dst, v);
-                } else {
-                    v += bv;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = tanhf(v);
-                    if (p.accumulate) v += *dst;
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + (wn * TN + j) * 32 + 8 * q + 4 * h;
+                    if (!(interior || col < p.N)) continue;  // N % 4 == 0: a quad is inside or outside as a whole
+                    float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    if (p.bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+                        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                    }
+                    if (p.act == 1) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    } else if (p.act == 2) {
+                        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+                    }
+                    float4* dst = reinterpret_cast<float4*>(drow + col);
+                    if (p.accumulate) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
                     *dst = v;
                 }
             }
         }
     }
+}
+
+// can this product use the 16-byte (SWAP) epilogue?
+inline bool gemm_vec_epilogue_ok(const GemmParams& p) {
+    return p.split_k <= 1 && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0 &&
+           (p.bias == nullptr || ((uintptr_t)p.bias % 16) == 0);
 }
 
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16.hip

@@ -58,7 +58,21 @@ def run(label, M, N, K, akm, bkm, acc, iters=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * M * N * K / ms / 1e9
-    print("%s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s  (%4.1f%% of %.1f)" % (label, M, N, K, ms * 1e3, tf, tf / PEAK * 100, PEAK))
+    yard = ""
+    if os.environ.get("DVAE_GEMM_YARDSTICK") == "1" and not BF16:
+        # the vendor library on the same product (torch.mm -> hipBLASLt / rocBLAS), as a yardstick only
+        a2 = A.t() if akm else A
+        b2 = B if bkm else B.t()
+        out = torch.empty(M, N, device="cuda")
+        for _ in range(3):
+            torch.mm(a2, b2, out=out)
+        e0.record(st)
+        for _ in range(iters):
+            torch.mm(a2, b2, out=out)
+        e1.record(st)
+        torch.cuda.synchronize()
+        yard = "   | torch.mm %8.1f us" % (e0.elapsed_time(e1) / iters * 1e3)
+    print("%s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s  (%4.1f%% of %.1f)%s" % (label, M, N, K, ms * 1e3, tf, tf / PEAK * 100, PEAK, yard))
 
 
 if __name__ == "__main__":
