@@ -98,6 +98,43 @@ def test_gemm_wgrad_splitk(rows, N, K):
     assert (out - ref).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
 
 
+@pytest.mark.parametrize("case", ["n_not_mult4", "ldc_not_mult4", "bias_unaligned", "c_unaligned"])
+def test_gemm_epilogue_paths_agree(case):
+    """the 16-byte (transposed-accumulation) epilogue needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C / bias;
+    each violation must fall back to the dword epilogue and give the same numbers"""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, K = 333, 96
+    N = 30 if case == "n_not_mult4" else 72
+    X = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias_store = torch.randn(N + 4, device="cuda", generator=g)
+    bias = bias_store[1:N + 1] if case == "bias_unaligned" else bias_store[:N]
+    ldc = N + 2 if case == "ldc_not_mult4" else N + 4
+    store = torch.full((M * ldc + 8,), 0.5, device="cuda")
+    off = 1 if case == "c_unaligned" else 0
+    out = store[off:off + M * ldc].view(M, ldc)
+    for act, acc in ((0, 0), (1, 1), (2, 0)):
+        out.fill_(0.5)
+        _gemm(X, W, out, M, N, K, bias=bias, act=act, acc=acc)
+        y = _ref(X, W.t()) + bias
+        y = [y, torch.relu(y), torch.tanh(y)][act]
+        ref = torch.full((M, ldc), 0.5, device="cuda")
+        ref[:, :N] = y + (0.5 if acc else 0.0)
+        assert (out - ref).abs().max() < 2e-4          # padding columns [N, ldc) untouched
+
+
+@pytest.mark.parametrize("M,N,K,acc", [(9251, 512, 2048, 1), (7168, 32, 1024, 0), (129, 132, 4096, 1), (2048, 512, 9248, 1)])
+def test_gemm_tile_and_split_choices(M, N, K, acc):
+    """shapes on either side of the tile / split-K cost model's decisions, K-major B (dgrad form)"""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    Bm = torch.randn(K, N, device="cuda", generator=g)
+    out = torch.ones(M, N, device="cuda")
+    _gemm(A, Bm, out, M, N, K, bkm=1, acc=acc)
+    ref = _ref(A, Bm) + (1.0 if acc else 0.0)
+    assert (out - ref).abs().max() <= 1e-5 * K ** 0.5 * 4 + 1e-4
+
+
 def test_gemm_rejects_bad_shapes():
     A = torch.zeros(8, 48, device="cuda")
     out = torch.zeros(8, 8, device="cuda")

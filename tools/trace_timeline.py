@@ -21,7 +21,7 @@ def main():
     ks.sort()
     # steps are delimited by the fused Adam kernel
     ends = [i for i, k in enumerate(ks) if "FusedOptimizer" in k[3] or "multi_tensor_apply_kernel<at::native::(anonymous namespace)::FusedOpt" in k[3]]
-    adam = [i for i, k in enumerate(ks) if "multi_tensor_apply" in k[3]]
+    adam = [i for i, k in enumerate(ks) if "multi_tensor_apply" in k[3] or k[3].startswith("adam_kernel")]
     print("kernels", len(ks), "adam launches at", adam[-8:])
     if len(adam) < 2:
         return
