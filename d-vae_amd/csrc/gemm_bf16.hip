@@ -148,7 +148,7 @@ __device__ __forceinline__ bf16x8 frag_h(const __bf16* lds, int roff, int s, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves");
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
                 if (s == 1) {
                     // mid-step: staged registers (tile t+1) -> LDS[cur^1], then issue the loads of tile t+2
                     la.store(lds + (cur ^ 1) * STAGE, tile(t + 1), kend, tid);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             cur ^= 1;
         }
     }
-    store_acc<TM, TN, false>(p, acc, m0, n0, wm, wn, lane, BM, BN);
+    store_acc<TM, TN, SWAP>(p, acc, m0, n0, wm, wn, lane, BM, BN);  // SWAP: transposed accumulation, 16-byte epilogue (gemm_common.h)
     }  // tiles
 }
 
@@ -239,11 +240,18 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
     dim3 block(256);
     const bool kg = bkm && p.b_rows != nullptr;
     if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, p);
-    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, p);
-    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, false>), grid, block, 0, s, p);
-    else if (akm && bkm && kg) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, true>), grid, block, 0, s, p);
+#define DVAE_GEMM_LAUNCH(A_, B_, G_)                                                                              \
+    do {                                                                                                          \
+        if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_, B_, G_, true>), grid, block, 0, s, p);  \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_, B_, G_, false>), grid, block, 0, s, p);     \
+    } while (0)
+    const bool vec = gemm_vec_epilogue_ok(p);
+    if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
+    else if (!akm && bkm && !kg) DVAE_GEMM_LAUNCH(false, true, false);
+    else if (akm && bkm && !kg) DVAE_GEMM_LAUNCH(true, true, false);
+    else if (akm && bkm && kg) DVAE_GEMM_LAUNCH(true, true, true);
     else return set_err(DVAE_ERR_ARG, "gemm: this operand layout / gather combination is not built");
+#undef DVAE_GEMM_LAUNCH
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
