@@ -20,14 +20,27 @@ struct CopyOps {
     int accumulate;  // dst += src
 };
 
-__global__ void copy_ops_kernel(CopyOps ops) {
+// grid (COPY_WGS, ops): a workgroup walks whole rows of its op, its threads the columns of a row
+// (coalesced on both sides, no division per element; H = 501 leaves the source rows unaligned, so
+// the accesses stay one float wide)
+constexpr int COPY_WGS = 256;
+__global__ __launch_bounds__(256) void copy_ops_kernel(CopyOps ops) {
     const CopyOp& o = ops.op[blockIdx.y];
-    long total = (long)o.rows * o.cols;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int r = (int)(i / o.cols), c = (int)(i % o.cols);
-        float v = o.src[(long)r * o.src_ld + c];
-        float* d = o.dst + (long)r * o.dst_ld + c;
-        *d = ops.accumulate ? *d + v : v;
+    const int rows = o.rows, cols = o.cols;
+    if (rows == 1) {  // a bias vector: spread its columns over the workgroups
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < cols; c += COPY_WGS * 256) {
+            const float v = o.src[c];
+            o.dst[c] = ops.accumulate ? o.dst[c] + v : v;
+        }
+        return;
+    }
+    for (int r = blockIdx.x; r < rows; r += COPY_WGS) {
+        const float* sp = o.src + (long)r * o.src_ld;
+        float* dp = o.dst + (long)r * o.dst_ld;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float v = sp[c];
+            dp[c] = ops.accumulate ? dp[c] + v : v;
+        }
     }
 }
 
@@ -171,7 +184,7 @@ static int block_ops(const Dims& d, const PackedLayout& L, float* const* nat, fl
 
 static int run_ops(const CopyOps& ops, hipStream_t s) {
     if (ops.n == 0) return DVAE_OK;
-    hipLaunchKernelGGL(copy_ops_kernel, dim3(64, ops.n), dim3(256), 0, s, ops);
+    hipLaunchKernelGGL(copy_ops_kernel, dim3(COPY_WGS, ops.n), dim3(256), 0, s, ops);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
