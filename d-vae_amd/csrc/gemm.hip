@@ -32,12 +32,7 @@
 
 namespace dvae {
 
-#ifndef DVAE_GEMM_BK
-#define DVAE_GEMM_BK 32
-#endif
-constexpr int BK = DVAE_GEMM_BK;
-constexpr int C4R = BK / 4;  // float4 chunks per K-contiguous tile row
-constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
+constexpr int BK0 = 32;  // K step of the default kernels; the unit of the host-side K arithmetic
 
 // Register-staged tile loader.  Everything that does not depend on the K step
 // (row gather, row clamping, column guards) is resolved ONCE in init(); the K loop
@@ -45,8 +40,10 @@ constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
 // them.  The staging registers and row pointers are NAMED scalars (r0..r3, p0..p3),
 // not arrays: as arrays hipcc left them in scratch memory across the loop back-edge
 // (scratch_store / scratch_load of every staged tile, ScratchSize 144 B/lane).
-template <int ROWS, bool KMAJOR, bool KGATHER>
+template <int ROWS, bool KMAJOR, bool KGATHER, int BK>
 struct TileLoader {
+    static constexpr int C4R = BK / 4;    // float4 chunks per K-contiguous tile row
+    static constexpr int KC_LD = BK + 4;  // K-contiguous LDS row stride (floats)
     static constexpr int UNITS = ROWS * BK / 4 / 256;  // float4 units per thread: 1, 2 or 4
     static constexpr int LDS_ELEMS = KMAJOR ? BK * ROWS : ROWS * KC_LD;
     static_assert(UNITS == 1 || UNITS == 2 || UNITS == 4, "tile rows must be 32, 64 or 128");
@@ -153,26 +150,23 @@ struct TileLoader {
             *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + k * ROWS + m4 * 4, 16)) = v;
         }
     }
-    // unit i alone: registers -> LDS image, then the same registers are reloaded from tile k0
-    // (i is a constant after unrolling; a switch over named registers keeps them out of scratch)
-    __device__ __forceinline__ void restage(int i, float* lds, int k0, int kend, int tid) {
+    // unit i alone: registers -> LDS image (stage_store), then the same registers are reloaded
+    // from tile k0 (stage_load).  i is a constant after unrolling; a switch over named registers
+    // keeps them out of scratch.
+    __device__ __forceinline__ void stage_store(int i, float* lds, int tid) {
         switch (i) {
-        case 0:
-            store1(lds, 0, tid, r0);
-            r0 = KMAJOR ? kload(0, k0, kend, tid, c0, col0_, n0_) : *reinterpret_cast<const float4*>(p0 + k0);
-            break;
-        case 1:
-            store1(lds, 1, tid, r1);
-            r1 = KMAJOR ? kload(1, k0, kend, tid, c1, col1_, n1_) : *reinterpret_cast<const float4*>(p1 + k0);
-            break;
-        case 2:
-            store1(lds, 2, tid, r2);
-            r2 = KMAJOR ? kload(2, k0, kend, tid, c2, col2_, n2_) : *reinterpret_cast<const float4*>(p2 + k0);
-            break;
-        default:
-            store1(lds, 3, tid, r3);
-            r3 = KMAJOR ? kload(3, k0, kend, tid, c3, col3_, n3_) : *reinterpret_cast<const float4*>(p3 + k0);
-            break;
+        case 0: store1(lds, 0, tid, r0); break;
+        case 1: store1(lds, 1, tid, r1); break;
+        case 2: store1(lds, 2, tid, r2); break;
+        default: store1(lds, 3, tid, r3); break;
+        }
+    }
+    __device__ __forceinline__ void stage_load(int i, int k0, int kend, int tid) {
+        switch (i) {
+        case 0: r0 = KMAJOR ? kload(0, k0, kend, tid, c0, col0_, n0_) : *reinterpret_cast<const float4*>(p0 + k0); break;
+        case 1: r1 = KMAJOR ? kload(1, k0, kend, tid, c1, col1_, n1_) : *reinterpret_cast<const float4*>(p1 + k0); break;
+        case 2: r2 = KMAJOR ? kload(2, k0, kend, tid, c2, col2_, n2_) : *reinterpret_cast<const float4*>(p2 + k0); break;
+        default: r3 = KMAJOR ? kload(3, k0, kend, tid, c3, col3_, n3_) : *reinterpret_cast<const float4*>(p3 + k0); break;
         }
     }
     __device__ __forceinline__ void store(float* lds, int tid) {
@@ -187,8 +181,9 @@ struct TileLoader {
 
 // fragment fetch for one 8-k group g: 4 values (MFMA i = 0..3) for the 32-row
 // sub-tile starting at row `roff`
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int BK>
 __device__ __forceinline__ float4 frag(const float* lds, int roff, int g, int lane) {
+    constexpr int KC_LD = BK + 4;
     int h = lane >> 5, r = roff + (lane & 31);
     if (!KMAJOR) {
         return *reinterpret_cast<const float4*>(lds + r * KC_LD + g * 8 + 4 * h);
@@ -198,12 +193,12 @@ __device__ __forceinline__ float4 frag(const float* lds, int roff, int g, int la
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves");
-    using LA = TileLoader<BM, AKM, false>;  // only the B operand of a weight-gradient product is row-gathered along K
-    using LB = TileLoader<BN, BKM, KGATHER>;
+    using LA = TileLoader<BM, AKM, false, BK>;  // only the B operand of a weight-gradient product is row-gathered along K
+    using LB = TileLoader<BN, BKM, KGATHER, BK>;
     __shared__ __attribute__((aligned(16))) float lds[2 * (LA::LDS_ELEMS + LB::LDS_ELEMS)];
     constexpr int STAGE = LA::LDS_ELEMS + LB::LDS_ELEMS;  // one stage: A image then B image
 
@@ -260,12 +255,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int NU = LA::UNITS + LB::UNITS;
     constexpr int SLOTS = (NG - 1) * TM * TN;
     constexpr int UPS = (NU + SLOTS - 1) / SLOTS;  // staging units per slot
+    static_assert(UPS <= 2, "a slot stages at most two units");
     static_assert(NG % 2 == 0, "fragment double buffer assumes an even number of groups per step");
     float4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = frag<BM, AKM>(lds, (wm * TM + i) * 32, 0, lane);
+    for (int i = 0; i < TM; ++i) fa[0][i] = frag<BM, AKM, BK>(lds, (wm * TM + i) * 32, 0, lane);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = frag<BN, BKM>(lds + LA::LDS_ELEMS, (wn * TN + j) * 32, 0, lane);
+    for (int j = 0; j < TN; ++j) fb[0][j] = frag<BN, BKM, BK>(lds + LA::LDS_ELEMS, (wn * TN + j) * 32, 0, lane);
     int cur = 0, t = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK, ++t) {
         float* nl = lds + (cur ^ 1) * STAGE;
@@ -274,9 +270,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const float* src = (g < NG - 1) ? lds + cur * STAGE : nl;
             const int gn = (g + 1) % NG;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = frag<BM, AKM>(src, (wm * TM + i) * 32, gn, lane);
+            for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = frag<BM, AKM, BK>(src, (wm * TM + i) * 32, gn, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = frag<BN, BKM>(src + LA::LDS_ELEMS, (wn * TN + j) * 32, gn, lane);
+            for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = frag<BN, BKM, BK>(src + LA::LDS_ELEMS, (wn * TN + j) * 32, gn, lane);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -285,21 +281,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     // SWAP: the block is accumulated transposed (same products, same k order), which
                     // gives each lane 4 consecutive columns of one row for the epilogue
                     const float4 a4 = SWAP ? fb[g & 1][j] : fa[g & 1][i], b4 = SWAP ? fa[g & 1][i] : fb[g & 1][j];
+                    // one staging slot per MFMA quad of groups 0..NG-2: up to two units, each
+                    // "registers -> LDS[cur^1]" behind one MFMA and "reload from tile k+2" behind the
+                    // next, so that a wave alone on its SIMD issues them in the MFMAs' shadow
+                    const int slot = (g * TM + i) * TN + j;
+                    const int u0 = slot * UPS, u1 = slot * UPS + 1;
+                    const bool on0 = g < NG - 1 && u0 < NU, on1 = g < NG - 1 && UPS > 1 && u1 < NU;
+                    auto st = [&](int u) {
+                        if (u < LA::UNITS) la.stage_store(u, nl, tid);
+                        else lb.stage_store(u - LA::UNITS, nl + LA::LDS_ELEMS, tid);
+                    };
+                    auto ld = [&](int u) {
+                        if (u < LA::UNITS) la.stage_load(u, tile(t + 2), kend, tid);
+                        else lb.stage_load(u - LA::UNITS, tile(t + 2), kend, tid);
+                        if (u == NU - 1) lb.next_idx(tile(t + 3), kend, tid);
+                    };
+                    // K-major operand pairs (weight gradients: buffer loads, b32 fragment reads) gain
+                    // 10-15 % from placing each store / reload behind its own MFMA; K-contiguous
+                    // ones run 1 % faster with the quad kept whole (measured both ways)
+                    constexpr bool FINE = AKM && BKM;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[i][j], 0, 0, 0);
+                    if (FINE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (on0) st(u0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[i][j], 0, 0, 0);
+                    if (FINE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (on0) ld(u0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[i][j], 0, 0, 0);
+                    if (FINE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (on1) st(u1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[i][j], 0, 0, 0);
-                    if (g < NG - 1) {
-                        const int slot = (g * TM + i) * TN + j;
-#pragma unroll
-                        for (int q = 0; q < UPS; ++q) {
-                            const int u = slot * UPS + q;
-                            if (u < NU) {
-                                if (u < LA::UNITS) la.restage(u, nl, tile(t + 2), kend, tid);
-                                else lb.restage(u - LA::UNITS, nl + LA::LDS_ELEMS, tile(t + 2), kend, tid);
-                                if (u == NU - 1) lb.next_idx(tile(t + 3), kend, tid);
-                            }
-                        }
+                    if (FINE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (on1) ld(u1);
+                    } else {
+                        if (on0) { st(u0); ld(u0); }
+                        if (on1) { st(u1); ld(u1); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -312,20 +337,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }  // tiles
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_cfg(GemmParams p, int akm, int bkm, hipStream_t s) {
     p.tiles_x = cdiv(p.N, BN);
     p.tiles_y = cdiv(p.M, BM);
     const long ntiles = (long)p.tiles_x * p.tiles_y;
-    const long cap = (BM * BN >= 128 * 128 ? 512 : 1024);  // co-resident workgroups the chip holds (multiple of 8: XCD runs)
+    const long cap = (BM * BN * BK >= 64 * 64 * 64 ? 512 : 1024);  // co-resident workgroups the chip holds (multiple of 8: XCD runs)
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, p.split_k > 1 ? p.split_k : 1);
     dim3 block(256);
     const bool kg = bkm && p.b_rows != nullptr;
     if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");
 #define DVAE_GEMM_LAUNCH(A_, B_, G_)                                                                             \
     do {                                                                                                         \
-        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, true>), grid, block, 0, s, p);  \
-        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, false>), grid, block, 0, s, p);     \
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, true, BK>), grid, block, 0, s, p);  \
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_, B_, G_, false, BK>), grid, block, 0, s, p);     \
     } while (0)
     const bool vec = gemm_vec_epilogue_ok(p);
     if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
@@ -402,7 +427,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
                 d.c_rows != nullptr);
     if (d.M == 0 || d.N == 0) return DVAE_OK;
     {
-        const int kc = gemm_k_chunk(d, BK);
+        const int kc = gemm_k_chunk(d, BK0);
         if (kc < 0) return kc;
         if (kc < d.K) {
             dvae_gemm_desc sub;
@@ -433,7 +458,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     // may split K over workgroups that combine with fp32 atomics.
     long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     long t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
-    int ksteps = cdiv(d.K, BK);
+    int ksteps = cdiv(d.K, BK0);
     bool small_m = d.M <= 32 && d.a_kmajor;
     const bool may_split = d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 8;
     bool use128 = false;
@@ -475,12 +500,14 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     if (knob_split > 0 && may_split) best = knob_split < ksteps ? knob_split : ksteps;
     if (best < 1) best = 1;
     if (best > 1) {
-        p.k_per_split = cdiv(ksteps, best) * BK;
+        p.k_per_split = cdiv(ksteps, best) * BK0;
         p.split_k = cdiv(d.K, p.k_per_split);
     }
-    if (small_m) return launch_cfg<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
-    if (use128) return launch_cfg<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
-    return launch_cfg<64, 64, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
+    // (a K step of 64 for the 64x64 tile was measured too: 6 % on the 1.5-tiles-per-CU GRU product,
+    // nothing elsewhere, 1 % slower train step; only the 32-k kernels are built)
+    if (small_m) return launch_cfg<32, 128, 1, 4, 32>(p, d.a_kmajor, d.b_kmajor, s);
+    if (use128) return launch_cfg<128, 128, 2, 2, 32>(p, d.a_kmajor, d.b_kmajor, s);
+    return launch_cfg<64, 64, 2, 2, 32>(p, d.a_kmajor, d.b_kmajor, s);
 }
 
 }  // namespace dvae
