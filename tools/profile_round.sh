@@ -1,0 +1,21 @@
+# Collects the round's profile artifacts into gpurun_out/prof/ (run on the GPU box through gpurun).
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel stats of the bench workload, both matrix-unit modes
+for dt in f32 bf16; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$dt -o s -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype $dt > $O/stats_$dt.log 2>&1 || exit 1
+done
+# 2. PMC passes on the dominant GEMM launch, one counter group per run
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $c | tr ' ' '_')
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/tools/gemm_one.py 9251 2048 512 0 0 0 > $O/pmc_$tag.log 2>&1 || exit 1
+done
+cd $R
+# 3. plain runs
+timeout -k 10 300 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err || exit 1
+timeout -k 10 300 python bench.py --dtype bf16 > $O/bench_cfg2_bf16.json 2> $O/bench_cfg2_bf16.err || exit 1
+timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_fp32.txt 2>&1 || exit 1
+DVAE_GEMM_BF16=1 timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_bf16.txt 2>&1 || exit 1
+timeout -k 10 100 python tools/phase_times.py > $O/phase_times_cfg2.txt 2>&1 || exit 1
