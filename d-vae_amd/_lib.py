@@ -20,7 +20,7 @@ class ModelDesc(C.Structure):
 class BatchCounts(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("B", "n", "T", "is_bn", "nB", "E", "PT", "PL", "NA", "NB", "NP", "CA", "CH", "CC",
-                 "R", "RL", "NCE", "HGF", "HGB", "pad_")] + [("total_ints", C.c_int64)]
+                 "R", "RL", "NCE", "HGF", "HGB", "level_major")] + [("total_ints", C.c_int64)]
 
 
 class GemmDesc(C.Structure):

@@ -289,6 +289,16 @@ static int build(PackedBatch& pb, int B, int n, int T, int start_type, int is_bn
             for (int k = vs_off[r]; k < vs_off[r + 1]; ++k) vst_idx[pos[vs_idx[k]]++] = r;
     }
 
+    // level-major batch: all graphs full size, EA rows = the slots of levels 0..n-2 in order, one
+    // vertex-type row per (level, graph) in level order
+    {
+        bool reg = !is_bn && n >= 2;
+        for (int b = 0; b < B && reg; ++b) reg = n_g[b] == n;
+        reg = reg && c.NA == (n - 1) * B && c.R == (n - 1) * B && c.RL == c.R;
+        for (int i = 0; i < c.NA && reg; ++i) reg = rowsA[i] == i;
+        for (int i = 0; i < c.R && reg; ++i) reg = vs_idx[i] == i;
+        c.level_major = reg ? 1 : 0;
+    }
     c.total_ints = walk_batch(c, [](int, int64_t, int64_t) {});
     // sanity: every array has exactly the size the layout expects
     int bad = -1;

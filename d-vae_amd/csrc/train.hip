@@ -478,6 +478,11 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     const float* gi = pw + L.gi[2];
     const float* bhn = pw + L.bhn[2];
 
+    // level-major batches (every graph full size: all of the reference's data sets) run the
+    // per-level predictor products beside the chain
+    const bool by_level = !d.bn && c->level_major != 0;
+    Side* side = nullptr;
+    if (by_level) DVAE_TRY(side_for_current_device(&side));
     DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
     DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
@@ -503,6 +508,17 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
                                                 w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, B, Hp, s));
             }
+            if (by_level && v < n - 1) {
+                // The state of level v is final: its rows of the EA table and its vertex-type rows
+                // (graph state after v + 1 vertices) run now on the side stream, small launches that
+                // fill the CUs the latency-bound chain leaves idle (as the second encoder direction does).
+                hipStream_t s2 = side->stream;
+                DVAE_TRY(fork_side(side, s));
+                DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.w1a, Hp, nullptr, w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2));
+                DVAE_TRY(dvae_gather_sum_f32(w.vs + r0 * Hp, Hp, w.st, Hp, bv.vs_off + r0, bv.vs_idx, B, Hp, 0, s2));
+                DVAE_TRY(lin_fwd(w.vs + r0 * Hp, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1 + r0 * d.HVp, d.HVp, B, d.HVp,
+                                 Hp, 1, 0, s2));
+            }
             if (v < n - 1) {
                 float* gm = w.gm + r0 * 2 * Hp;
                 DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
@@ -519,17 +535,21 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                                         Hp, w.ghn + p0 * Hp, PT, Hp, s));
     }
     // edge predictor: first layer split over its inputs
-    DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
+    if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
     DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s));
     DVAE_HIP(hipMemsetAsync(w.ea + (size_t)c->NA * HEp, 0, sizeof(float) * HEp, s));
     DVAE_HIP(hipMemsetAsync(w.eb + (size_t)c->NB * HEp, 0, sizeof(float) * HEp, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
+    if (by_level) DVAE_TRY(join_side(side, s));
     DVAE_TRY(dvae_pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t,
                                pw + L.be1, pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, w.dw2_blocks,
                                c->NP, HEp, s));
     // vertex-type predictor
-    DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
-    DVAE_TRY(lin_fwd(w.vs, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1, d.HVp, c->R, d.HVp, Hp, 1, 0, s));
+    if (!by_level) {
+        DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
+        DVAE_TRY(lin_fwd(w.vs, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1, d.HVp, c->R, d.HVp, Hp, 1, 0, s));
+    }
+    // (the Tp-wide logits product stays one launch: a level's slice of it is 16 workgroups)
     DVAE_TRY(lin_fwd(w.v1, d.HVp, nullptr, pw + L.wv2, d.HVp, pw + L.bv2, w.logits, d.Tp, c->R, d.Tp, d.HVp, 0, 0, s));
     DVAE_TRY(dvae_vertex_ce(w.logits, d.Tp, bv.ce_off, bv.ce_tgt, w.dlogits, w.sums + 1, c->R, d.T, d.Tp, s));
     hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, s, w.sums, beta, out3);

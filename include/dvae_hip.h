@@ -205,7 +205,9 @@ typedef struct dvae_batch_counts {
     int32_t CA, CH, CC;  /* backward chunks grouped by EA row / EB row / graph    */
     int32_t R, RL, NCE;  /* vertex-type rows, their source-list length, CE items  */
     int32_t HGF, HGB;    /* graph-state source-list lengths                      */
-    int32_t pad_;
+    int32_t level_major; /* 1: every graph has n vertices, so the rows of the EA table and the
+                            vertex-type rows of level v are [v B, (v+1) B): the loss forward then
+                            runs those products level by level beside the state chain            */
     int64_t total_ints;  /* size of the exported index blob, in int32            */
 } dvae_batch_counts;
 
