@@ -72,6 +72,24 @@ def test_packer_counts_and_dedup():
         assert sorted(t[key + "_pairs"].tolist()) == list(range(c.NP))
 
 
+def test_packer_level_major_flag():
+    """full-size batches (the reference's data sets) are flagged level-major: EA row i and vertex-type row i are
+    slot i, which lets the loss forward run those products level by level; ragged or BN batches are not"""
+    d, cls, ctor = load_case(golden_files("dvae_cfg1_uni")[0])
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    b = dvae_amd.DAGBatch(ga, 8, 0, False, "cpu")
+    assert b.counts.level_major == 1
+    t = BI.unpack_blob(b)
+    assert t["rowsA"].tolist() == list(range(b.counts.NA)) and b.counts.NA == 32 * 7
+    assert t["vs_idx"].tolist() == list(range(b.counts.R))
+    d, cls, ctor = load_case(golden_files("dvae_tiny_bi_var")[0])
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    assert dvae_amd.DAGBatch(ga, ctor["nvt"], 0, False, "cpu").counts.level_major == 0
+    d, cls, ctor = load_case(golden_files("bn_tiny_uni_full")[0])
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    assert dvae_amd.DAGBatch(ga, ctor["nvt"], 0, True, "cpu").counts.level_major == 0
+
+
 def test_graph_objects_and_arrays_agree():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "oracle", "igraph_standin"))
