@@ -278,17 +278,33 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     // Tile / split-K choice: as for the fp32 kernel.  A bf16 K step is 16x cheaper on the matrix
     // pipe, so these products are bound by operand traffic and launch latency: prefer many
     // workgroups (two or more per CU) over long K loops.
+    static const int knob_tile = getenv("DVAE_GEMM_TILE") ? atoi(getenv("DVAE_GEMM_TILE")) : 0;    // tools/gemm_tune.py
+    static const int knob_split = getenv("DVAE_GEMM_SPLIT") ? atoi(getenv("DVAE_GEMM_SPLIT")) : 0;
     long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     long t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
-    bool use128 = t128 >= 384 || (d.a_kmajor && t128 >= 24);
+    bool use128 = t128 >= 384 || (d.a_kmajor && t128 >= 64);
     int ksteps = cdiv(d.K, BKH);
-    const bool small_m = d.M <= 32 && d.a_kmajor;
+    bool small_m = d.M <= 32 && d.a_kmajor;
+    if (knob_tile == 128) { use128 = true; small_m = false; }
+    else if (knob_tile == 64) { use128 = false; small_m = false; }
+    else if (knob_tile == 32) small_m = true;
     if (d.accumulate && d.bias == nullptr && d.act == 0 && ksteps >= 4) {
         long tiles = small_m ? (long)cdiv(d.N, 128) : (use128 ? t128 : t64);
         long target = use128 && !small_m ? 512 : 256;  // small tiles: measured best at one workgroup per CU
         int want = (int)((target + tiles - 1) / tiles);
         int maxsplit = ksteps / 2;
         int sk = want < maxsplit ? want : maxsplit;
+        if (!use128 && !small_m && d.a_kmajor && d.b_kmajor) {
+            // weight gradients on 64x64 tiles (tools/gemm_tune.py, DVAE_GEMM_BF16=1): whole rounds of
+            // 256 workgroups, at least two per CU
+            double best_cost = -1.0;
+            for (int k = 1; k <= 8 && k <= maxsplit; ++k) {
+                const long wgs = tiles * k;
+                const double cost = (double)((wgs + 255) / 256) * (cdiv(ksteps, k) + 6) * (wgs < 512 ? 1.25 : 1.0);
+                if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; sk = k; }
+            }
+        }
+        if (knob_split > 0) sk = knob_split < ksteps ? knob_split : ksteps;
         if (sk > 1) {
             p.k_per_split = cdiv(ksteps, sk) * BKH;
             p.split_k = cdiv(d.K, p.k_per_split);

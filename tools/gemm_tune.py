@@ -5,7 +5,7 @@
 
 `log` runs one step with DVAE_GEMM_LOG=1 in a child process and counts the distinct products;
 `sweep` times each of them under DVAE_GEMM_TILE / DVAE_GEMM_SPLIT overrides, one child process per
-override pair (the knobs are read once per process)."""
+override pair (the knobs are read once per process).  DVAE_GEMM_BF16=1 tunes the bf16-input kernel."""
 import collections
 import os
 import subprocess
@@ -21,7 +21,7 @@ def child_step(cfg):
     import bench
     from _dvae_pkg import dvae_amd  # noqa: F401
     c = bench.CONFIGS[cfg]
-    model = bench.make_model(c, 1, "fp32").cuda()
+    model = bench.make_model(c, 1, "bf16" if os.environ.get("DVAE_GEMM_BF16") == "1" else "fp32").cuda()
     ga = bench.make_graphs(c, c["B"], 0)
     batch = model._collate_fn(ga)
     model.train()
@@ -67,12 +67,13 @@ def child_time(shapes_file):
             r = torch.randperm(M, device="cuda", generator=gen).int(); keep.append(r); d.c_rows = r.data_ptr()
         st = torch.cuda.current_stream()
         sp = C.c_void_p(st.cuda_stream)
+        fn = lib.dvae_gemm_bf16 if os.environ.get("DVAE_GEMM_BF16") == "1" else lib.dvae_gemm_f32
         for _ in range(3):
-            L.check(lib.dvae_gemm_f32(C.byref(d), sp))
+            L.check(fn(C.byref(d), sp))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         for _ in range(20):
-            lib.dvae_gemm_f32(C.byref(d), sp)
+            fn(C.byref(d), sp)
         e1.record(st)
         torch.cuda.synchronize()
         print("T %s | %.2f" % (" ".join(f[1:]), e0.elapsed_time(e1) / 20 * 1e3), flush=True)
