@@ -78,6 +78,7 @@ struct TileLoader {
                                          int rdim, int tid) {
         rows_ = rows;
         ld_ = ld;
+        lo_ = KMAJOR ? (tid / (ROWS / 4)) * ROWS + (tid % (ROWS / 4)) * 4 : (tid / C4R) * KC_LD + (tid % C4R) * 4;
         if (KMAJOR) rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, OOB, 0x00020000);
         init1(p0, c0, col0_, 0, base, rows, ld, r0_, rdim, tid);
         if (UNITS > 1) init1(p1, c1, col1_, 1, base, rows, ld, r0_, rdim, tid);
@@ -139,16 +140,13 @@ struct TileLoader {
             }
         }
     }
-    __device__ __forceinline__ static void store1(float* lds, int i, int tid, float4 v) {
-        int u = tid + 256 * i;
-        if (!KMAJOR) {
-            int row = u / C4R, c4 = u % C4R;
-            // (the hint makes this one ds_write_b128; hipcc cannot prove the alignment and emits two b64)
-            *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + row * KC_LD + c4 * 4, 16)) = v;
-        } else {
-            int k = u / (ROWS / 4), m4 = u % (ROWS / 4);
-            *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + k * ROWS + m4 * 4, 16)) = v;
-        }
+    // LDS position of unit i = this thread's base (computed once in init) + a compile-time step,
+    // so a store is one ds_write_b128 with an immediate offset and no address arithmetic in the loop
+    int lo_;
+    __device__ __forceinline__ void store1(float* lds, int i, int tid, float4 v) const {
+        constexpr int STEP = KMAJOR ? 1024 : (256 / C4R) * KC_LD;  // floats between consecutive units
+        // (the hint makes this one ds_write_b128; hipcc cannot prove the alignment and emits two b64)
+        *reinterpret_cast<float4*>(__builtin_assume_aligned(lds + lo_ + i * STEP, 16)) = v;
     }
     // unit i alone: registers -> LDS image (stage_store), then the same registers are reloaded
     // from tile k0 (stage_load).  i is a constant after unrolling; a switch over named registers
