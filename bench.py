@@ -34,10 +34,10 @@ from _dvae_pkg import dvae_amd  # noqa: E402
 PEAK_F32_TFLOPS = 157.3    # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # Memory-side traffic of one launch of the dominant GEMM on its cfg-2 shape (9251 x 2048 x 512),
-# from rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE 77542 KB, doubled per the gfx950
-# correction of MI355X_MICROARCH.md (section HBM), + WRITE_SIZE 74031 KB (profiles/r01_gemm_pmc.json).  Infinity-Cache hits are
+# from rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE 58717 KB, doubled per the gfx950
+# correction of MI355X_MICROARCH.md (section HBM), + WRITE_SIZE 74037 KB (profiles/r01_gemm_pmc.json).  Infinity-Cache hits are
 # counted by these counters, so this is traffic behind L2, an upper bound on HBM bytes.
-MEASURED_TRAFFIC = {(9251, 2048, 512): (2 * 77542 + 74031) * 1024}
+MEASURED_TRAFFIC = {(9251, 2048, 512): (2 * 58717 + 74037) * 1024}
 
 CONFIGS = {
     # name: (class, ctor kwargs, per-GPU batch, generator)

@@ -25,13 +25,19 @@ struct GemmParams {
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
 // L2), so workgroup ids that are equal mod 8 share an L2.  Give each such group a contiguous
-// run of tiles (N fastest), so the tiles that re-read one A row block meet in one L2.
+// run of tiles, so the tiles that re-read one A row block meet in one L2 (4 MB per XCD).
 template <int BM, int BN>
 __device__ __forceinline__ void tile_origin(int orig, int nx, int nwg, int& m0, int& n0) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    m0 = (id / nx) * BM;
-    n0 = (id % nx) * BN;
+    // within the run: bands of 8 tile rows walked column by column, so the ~64 tiles an XCD works on
+    // at once form an 8 x 8 block (8 A panels + 8 B panels = 4 MB at K = 512) instead of 4 x 16
+    // (FETCH_SIZE of the 9251 x 2048 x 512 product 80.1 -> 58.7 MB counted, same run time)
+    const int ny = nwg / nx;
+    const int band = id / (8 * nx), rem = id % (8 * nx);
+    const int rows_in_band = ny - band * 8 < 8 ? ny - band * 8 : 8;
+    m0 = (band * 8 + rem % rows_in_band) * BM;
+    n0 = (rem / rows_in_band) * BN;
 }
 
 // Epilogue.  The MFMA leaves D[i][j] with j = lane & 31 and i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
