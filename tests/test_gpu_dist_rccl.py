@@ -50,6 +50,11 @@ def test_rccl_one_rank_exchange_is_identity_and_overlapped_part_is_launched():
             torch.cuda.synchronize()
             assert reducer._early is None
         assert launched == [True, True]
+        # the few-float logging all-reduce (loss, recon, kld) over RCCL: one rank -> unchanged, float64
+        tot = reducer.reduce_scalars(loss, loss * 0.5, torch.tensor(3.0, device="cuda"))
+        assert tot.dtype == torch.float64 and tot.is_cuda
+        assert torch.allclose(tot, torch.stack([loss.detach().double(), loss.detach().double() * 0.5,
+                                                torch.tensor(3.0, device="cuda", dtype=torch.float64)]))
         ref.zero_grad()
         mu, lv = ref.encode(ga)
         l2, _, _ = ref.loss(mu, lv, ga, eps=eps)
