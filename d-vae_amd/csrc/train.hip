@@ -654,16 +654,21 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                             w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
             DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
         }
-        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB, 2 * Hp, Hp, s));
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
     }
-    DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, s));
+    // the GRU's weight gradients (the largest products of this tail) go to the side stream, behind
+    // the predictors' (long finished); the gate/mapper ones and the head stay here
+    DVAE_TRY(fork_side(side, s));
+    DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
     // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------
     EW(tanh_bwd_kernel, (long)B * Hp, w.dagg, w.agg, (long)B * Hp);
     DVAE_TRY(dvae_segment_colsum_f32(pg + L.b3, Hp, w.dagg, Hp, B, B, Hp, s));
     DVAE_TRY(lin_wgrad(w.dagg, Hp, w.z, d.NZp, nullptr, pg + L.fc3, d.NZp, B, Hp, d.NZp, s));
     DVAE_TRY(lin_dgrad(w.dagg, Hp, pw + L.fc3, d.NZp, w.dz, d.NZp, nullptr, B, Hp, d.NZp, 0, s));
     DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
+    if (!d.bn) {
+        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB, 2 * Hp, Hp, s));
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
+    }
     DVAE_TRY(join_side(side, s));
     return DVAE_OK;
 }
