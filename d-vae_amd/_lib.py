@@ -57,6 +57,10 @@ SIGNATURES = {
     "dvae_gated_pointwise_bwd": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "dvae_gated_fwd_gather": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_gated_bwd_gather": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dvae_gru_level_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvae_gru_level_bwd": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "dvae_level_dgrad_acc": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "dvae_gated_level_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_segment_colsum_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "dvae_pair_mask_words": (C.c_int64, [_I, _I]),
     "dvae_pair_bce_fwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),

@@ -269,6 +269,18 @@ extern "C" int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batc
     return (int64_t)carve_dec(d, *c, nullptr).total;
 }
 
+// The chain levels of the fp32 mode run the fused level kernels of chain.hip (hidden product +
+// pointwise tail in one launch); DVAE_CHAIN_FUSED=0 falls back to GEMM + pointwise launches (A/B runs).
+static bool chain_fused(const Dims& d) {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
+    return knob != 0 && !d.bf16 && !d.bn;
+}
+// the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD
+static bool chain_fused_bwd(const Dims& d) {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 0; }();
+    return knob != 0 && !d.bf16 && !d.bn;
+}
+
 // =====================================================================================
 // encode
 // =====================================================================================
@@ -285,6 +297,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
     const int dirs = d.bidir ? 2 : 1;
+    const bool fused = chain_fused(d);
 
     // DVAE_BN has no recurrence: each direction is one batched pass over all levels.
     auto run_dir_bn = [&](int k, hipStream_t s) -> int {
@@ -308,17 +321,26 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0
             DVAE_HIP(hipMemsetAsync(agg, 0, sizeof(float) * (size_t)B * Hp, s));
             DVAE_HIP(hipMemsetAsync(gates, 0, sizeof(float) * (size_t)B * 3 * Hp, s));
-        } else {
+        } else if (!fused) {
             DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
         }
-        DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp, w.hs[k] + r0 * Hp,
-                                        Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
+        if (fused && step > 0)  // hidden product + GRU tail in one launch (chain.hip)
+            DVAE_TRY(dvae_gru_level_fwd(agg, Hp, pw + L.whh[k], pw + L.gi[k], bv.types + r0, pw + L.bhn[k], gates,
+                                        w.ghn[k] + r0 * Hp, w.hs[k] + r0 * Hp, Hp, B, Hp, s));
+        else
+            DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp,
+                                            w.hs[k] + r0 * Hp, Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
         if (step < n - 1) {
             const long r1 = (long)(k == 0 ? v + 1 : v - 1) * B;
             float* gm = w.gm[k] + r0 * 2 * Hp;
-            DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
-            DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0,
-                                           w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
+            if (fused) {  // gate/mapper product + its tail + the next level's predecessor sum
+                DVAE_TRY(dvae_gated_level_fwd(w.hs[k] + r0 * Hp, Hp, pw + L.wgm[k], pw + L.gv[k] + (size_t)v * 2 * Hp, gm,
+                                              w.msg[k], Hp, (int)r0, w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
+            } else {
+                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+                DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0,
+                                               w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
+            }
         }
         return DVAE_OK;
     };
@@ -369,6 +391,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, NZ2 = 2 * d.NZp;
     const int dirs = d.bidir ? 2 : 1;
+    const bool fused = chain_fused_bwd(d);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
     EW(join_mu_logvar_kernel, (long)B * NZ2, w.d12, dmu, dlogvar, B, d.nz, d.NZp);
@@ -417,11 +440,21 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         if (step < n - 1) {
             DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr,
                                            w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
-            DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+            if (!fused)
+                DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
         }
-        DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
+        if (fused && step < n - 1)  // d h += d gm [Wg | Wm] and the GRU pointwise backward in one launch (chain.hip)
+            DVAE_TRY(dvae_gru_level_bwd(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, 2 * Hp, pw + L.wgm[k], dhs, Hp,
+                                        w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
-        if (step > 0)
+        else
+            DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp,
+                                            Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B,
+                                            Hp, s));
+        if (step > 0 && fused)
+            DVAE_TRY(dvae_level_dgrad_acc(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, 3 * Hp, pw + L.whh[k], w.dagg[k] + r0 * Hp, Hp, B,
+                                          Hp, s));
+        else if (step > 0)
             DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
                                3 * Hp, Hp, 1, s));
         return DVAE_OK;
@@ -487,8 +520,13 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
-    DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
-    DVAE_TRY(dvae_gru_pointwise_fwd(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, s));
+    const bool fused = chain_fused(d);
+    if (fused) {
+        DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
+    } else {
+        DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
+        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, s));
+    }
     if (d.bn) {
         // no recurrence: messages depend on predecessor types only (models.py:1044-1062)
         const long r0 = B;
@@ -503,7 +541,10 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     } else {
         for (int v = 0; v < n; ++v) {
             const long r0 = (long)v * B;
-            if (v > 0) {
+            if (v > 0 && fused) {
+                DVAE_TRY(dvae_gru_level_fwd(w.agg + r0 * Hp, Hp, whh, gi, bv.types + r0, bhn, w.gates + r0 * 3 * Hp,
+                                            w.ghn + r0 * Hp, w.st + r0 * Hp, Hp, B, Hp, s));
+            } else if (v > 0) {
                 DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
                 DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
                                                 w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, B, Hp, s));
@@ -521,10 +562,16 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
             }
             if (v < n - 1) {
                 float* gm = w.gm + r0 * 2 * Hp;
-                DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
-                // pointwise tail + predecessor sum of vertex v + 1
-                DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0,
-                                               w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp, s));
+                if (fused) {
+                    DVAE_TRY(dvae_gated_level_fwd(w.st + r0 * Hp, Hp, pw + L.wgm[0], pw + L.gv[0] + (size_t)v * 2 * Hp, gm,
+                                                  w.msg, Hp, (int)r0, w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B,
+                                                  bv.pred_idx, B, Hp, s));
+                } else {
+                    DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+                    // pointwise tail + predecessor sum of vertex v + 1
+                    DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0,
+                                                   w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp, s));
+                }
             }
         }
         // partial states: non-recurrent, one batched pass
@@ -572,6 +619,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp, NST = nB + PT;
     const float* whh = pw + L.whh[2];
+    const bool fused = chain_fused_bwd(d);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
     hipLaunchKernelGGL(grad_scales_kernel, dim3(1), dim3(1), 0, s, g3, beta, w.gs);
@@ -648,11 +696,20 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                 DVAE_TRY(dvae_gated_bwd_gather(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp,
                                                bv.pt_off + r0, bv.pt_idx, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B,
                                                Hp, s));
-                DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+                if (!fused)
+                    DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
             }
-            DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,
-                                            w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
-            DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
+            if (fused && v < n - 1)
+                DVAE_TRY(dvae_gru_level_bwd(w.dgm + r0 * 2 * Hp, 2 * Hp, 2 * Hp, pw + L.wgm[0], dst, Hp, w.gates + r0 * 3 * Hp,
+                                            w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp,
+                                            w.dagg + r0 * Hp, Hp, B, Hp, s));
+            else
+                DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,
+                                                w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
+            if (fused)
+                DVAE_TRY(dvae_level_dgrad_acc(w.dgh + r0 * 3 * Hp, 3 * Hp, 3 * Hp, whh, w.dagg + r0 * Hp, Hp, B, Hp, s));
+            else
+                DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
         }
     }
     // the GRU's weight gradients (the largest products of this tail) go to the side stream, behind

@@ -114,6 +114,35 @@ int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, con
                           const int32_t* off2, const int32_t* idx2, const float* gm, float* dgm, int32_t rows,
                           int32_t Hp, void* stream);
 
+/* One level of the state chain in ONE launch (fp32 MFMA; csrc/chain.hip): the hidden product of
+ * torch.nn.GRUCell (models.py:670) and its pointwise part.  hprev [rows][Hp] (ld_hprev) is both
+ * the product's operand and h_prev; whh [3Hp][Hp] is the padded W_hh (r, z, n blocks); gi_tab /
+ * types / bhn as for dvae_gru_pointwise_fwd.  Writes gates [rows][3Hp] = (r, z, n), ghn_out
+ * [rows][Hp] = W_hn h + b_hn and hout.  The pre-activations never reach memory.  Equals
+ * dvae_gemm_f32 + dvae_gru_pointwise_fwd up to the summation order over K (two halves). */
+int dvae_gru_level_fwd(const float* hprev, int32_t ld_hprev, const float* whh, const float* gi_tab,
+                       const int32_t* types, const float* bhn, float* gates, float* ghn_out, float* hout,
+                       int32_t ld_hout, int32_t rows, int32_t Hp, void* stream);
+/* _gated (models.py:628-629) of a level in ONE launch: the product h [Wg | Wm]^T (wgm [2Hp][Hp]),
+ * its pointwise part (gm [rows][2Hp] = (g, m), msg[cur_row0 + r] = g * m) and the gather-sum of
+ * models.py:661-669 for the next level (next_agg nullable), with the arguments and the contract
+ * of dvae_gated_fwd_gather. */
+int dvae_gated_level_fwd(const float* h, int32_t ld_h, const float* wgm, const float* gv_row, float* gm, float* msg,
+                         int32_t ld_msg, int32_t cur_row0, float* next_agg, int32_t ld_agg, const int32_t* next_off,
+                         const int32_t* idx, int32_t rows, int32_t Hp, void* stream);
+
+/* Backward twins (csrc/chain.hip; deterministic, no atomics).  w [K][Hp] is an nn.Linear weight
+ * [out = K][in = Hp]; dy [rows][K].
+ *   dvae_level_dgrad_acc: dx[rows][Hp] += dy w           (the input gradient of the Linear)
+ *   dvae_gru_level_bwd:   dh += dy w, then the pointwise backward of torch.nn.GRUCell from dh in
+ *                         the same launch, with the arguments and outputs of dvae_gru_pointwise_bwd
+ *                         (dgh, dgin, dhprev). */
+int dvae_level_dgrad_acc(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dx, int32_t ld_dx,
+                         int32_t rows, int32_t Hp, void* stream);
+int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dh, int32_t ld_dh,
+                       const float* gates, const float* ghn, const float* hprev, int32_t ld_hprev, float* dgh,
+                       float* dgin, float* dhprev, int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream);
+
 /* out[seg][0:width] += sum over the seg_rows rows of segment seg of x */
 int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                             int32_t seg_rows, int32_t width, void* stream);

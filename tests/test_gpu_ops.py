@@ -478,3 +478,127 @@ def test_gemm_bf16_wgrad_splitk(rows, N, K):
     _gemm(dY, X, out2, N, K, rows, akm=1, bkm=1, acc=1, bf16=True)
     ref2 = _ref_bf16(dY.t(), X[:rows])
     assert (out2 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
+
+
+@pytest.mark.parametrize("rows,Hp", [(1024, 512), (100, 64), (7, 32), (333, 1024)])
+def test_gru_level_fused_matches_gemm_plus_pointwise(rows, Hp):
+    """chain.hip: hidden product + GRUCell tail in one launch == dvae_gemm_f32 followed by
+    dvae_gru_pointwise_fwd up to the summation order over K (tolerance 2e-5 absolute on O(1)
+    activations), and == torch.nn.GRUCell arithmetic in fp64 (1e-5)."""
+    g = torch.Generator().manual_seed(rows + Hp)
+    T = 8
+    hprev = torch.randn(rows, Hp, generator=g).cuda()
+    whh = (torch.randn(3 * Hp, Hp, generator=g) / Hp ** 0.5).cuda()
+    gi = torch.randn(T, 3 * Hp, generator=g).cuda()
+    bhn = torch.randn(Hp, generator=g).cuda()
+    types = torch.randint(0, T, (rows,), generator=g).int().cuda()
+    lib = L.load()
+    gates_ref = torch.full((rows, 3 * Hp), float("nan")).cuda()
+    _gemm(hprev, whh, gates_ref, rows, 3 * Hp, Hp)
+    hout_ref = torch.zeros(rows, Hp).cuda()
+    ghn_ref = torch.zeros(rows, Hp).cuda()
+    L.check(lib.dvae_gru_pointwise_fwd(gates_ref.data_ptr(), gi.data_ptr(), types.data_ptr(), bhn.data_ptr(),
+                                       hprev.data_ptr(), Hp, hout_ref.data_ptr(), Hp, ghn_ref.data_ptr(), rows, Hp, _s()))
+    gates = torch.full((rows, 3 * Hp), float("nan")).cuda()
+    hout = torch.full((rows, Hp), float("nan")).cuda()
+    ghn = torch.full((rows, Hp), float("nan")).cuda()
+    L.check(lib.dvae_gru_level_fwd(hprev.data_ptr(), Hp, whh.data_ptr(), gi.data_ptr(), types.data_ptr(), bhn.data_ptr(),
+                                   gates.data_ptr(), ghn.data_ptr(), hout.data_ptr(), Hp, rows, Hp, _s()))
+    torch.cuda.synchronize()
+    for a, b in ((gates, gates_ref), (ghn, ghn_ref), (hout, hout_ref)):
+        assert torch.isfinite(a).all() and (a - b).abs().max() < 2e-5
+    # fp64 GRUCell arithmetic
+    gh = hprev.double() @ whh.double().t()
+    gsel = gi.double()[types.long()]
+    r = torch.sigmoid(gsel[:, :Hp] + gh[:, :Hp])
+    z = torch.sigmoid(gsel[:, Hp:2 * Hp] + gh[:, Hp:2 * Hp])
+    nn_ = torch.tanh(gsel[:, 2 * Hp:] + r * (gh[:, 2 * Hp:] + bhn.double()))
+    assert (hout.double() - ((1 - z) * nn_ + z * hprev.double())).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("B,Hp,with_next", [(1024, 512, True), (50, 64, True), (70, 96, False)])
+def test_gated_level_fused_matches_gemm_plus_gather(B, Hp, with_next):
+    """chain.hip: gate/mapper product + pointwise tail + next level's predecessor sum in one launch ==
+    dvae_gemm_f32 followed by dvae_gated_fwd_gather (2e-5 absolute: summation order over K)."""
+    g = torch.Generator().manual_seed(B + Hp)
+    levels, cur = 4, 2
+    lib = L.load()
+    msg = torch.randn(levels * B, Hp, generator=g).cuda()
+    h = torch.randn(B, Hp, generator=g).cuda()
+    wgm = (torch.randn(2 * Hp, Hp, generator=g) / Hp ** 0.5).cuda()
+    gv = torch.randn(levels, 2 * Hp, generator=g).cuda()
+    off, idx = [0], []
+    for b in range(B):
+        ks = [u for u in range(cur + 1) if torch.rand((), generator=g) < 0.6]
+        idx += [u * B + b for u in ks]
+        off.append(len(idx))
+    off_d = torch.tensor(off, dtype=torch.int32).cuda()
+    idx_d = torch.tensor(idx + [0], dtype=torch.int32).cuda()
+    gm_ref = torch.full((B, 2 * Hp), float("nan")).cuda()
+    _gemm(h, wgm, gm_ref, B, 2 * Hp, Hp)
+    msg_ref = msg.clone()
+    agg_ref = torch.full((B, Hp), float("nan")).cuda()
+    L.check(lib.dvae_gated_fwd_gather(gm_ref.data_ptr(), gv[cur].data_ptr(), msg_ref.data_ptr(), Hp, cur * B,
+                                      agg_ref.data_ptr() if with_next else None, Hp, off_d.data_ptr(), idx_d.data_ptr(),
+                                      B, Hp, _s()))
+    gm_f = torch.full((B, 2 * Hp), float("nan")).cuda()
+    msg_f = msg.clone()
+    agg_f = torch.full((B, Hp), float("nan")).cuda()
+    L.check(lib.dvae_gated_level_fwd(h.data_ptr(), Hp, wgm.data_ptr(), gv[cur].data_ptr(), gm_f.data_ptr(),
+                                     msg_f.data_ptr(), Hp, cur * B, agg_f.data_ptr() if with_next else None, Hp,
+                                     off_d.data_ptr(), idx_d.data_ptr(), B, Hp, _s()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(gm_f).all() and (gm_f - gm_ref).abs().max() < 2e-5
+    assert (msg_f - msg_ref).abs().max() < 2e-5
+    # rows of other levels are untouched
+    assert torch.equal(msg_f[:cur * B], msg[:cur * B]) and torch.equal(msg_f[(cur + 1) * B:], msg[(cur + 1) * B:])
+    if with_next:
+        assert (agg_f - agg_ref).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("rows,Hp,K", [(1024, 512, 1536), (1024, 512, 1024), (100, 64, 128), (7, 32, 96), (130, 96, 288)])
+def test_level_dgrad_acc_matches_fp64(rows, Hp, K):
+    """chain.hip: dx += dy w (w K-major) against fp64; K % 64 == 32 exercises the half step."""
+    g = torch.Generator().manual_seed(rows + Hp + K)
+    dy = torch.randn(rows, K, generator=g).cuda()
+    w = (torch.randn(K, Hp, generator=g) / K ** 0.5).cuda()
+    dx0 = torch.randn(rows, Hp, generator=g).cuda()
+    dx = dx0.clone()
+    L.check(L.load().dvae_level_dgrad_acc(dy.data_ptr(), K, K, w.data_ptr(), dx.data_ptr(), Hp, rows, Hp, _s()))
+    torch.cuda.synchronize()
+    ref = dx0.double() + dy.double() @ w.double()
+    assert torch.isfinite(dx).all() and (dx.double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("rows,Hp", [(1024, 512), (100, 64), (37, 96)])
+def test_gru_level_bwd_fused_matches_dgrad_plus_pointwise(rows, Hp):
+    """chain.hip: dh += dgm [Wg|Wm] and the GRU pointwise backward in one launch == dvae_gemm_f32
+    (dgrad) followed by dvae_gru_pointwise_bwd (2e-5 absolute: summation order over K)."""
+    g = torch.Generator().manual_seed(rows * 3 + Hp)
+    K = 2 * Hp
+    lib = L.load()
+    dgm = torch.randn(rows, K, generator=g).cuda()
+    w = (torch.randn(K, Hp, generator=g) / K ** 0.5).cuda()
+    dh0 = torch.randn(rows, Hp, generator=g).cuda()
+    gates = torch.rand(rows, 3 * Hp, generator=g).cuda()
+    gates[:, 2 * Hp:] = gates[:, 2 * Hp:] * 2 - 1
+    ghn = torch.randn(rows, Hp, generator=g).cuda()
+    hprev = torch.randn(rows, Hp, generator=g).cuda()
+    # reference: accumulate dgrad, then pointwise backward
+    dh_ref = dh0.clone()
+    _gemm(dgm, w, dh_ref, rows, Hp, K, bkm=1, acc=1)
+    outs_ref = [torch.full((rows, 3 * Hp), float("nan")).cuda(), torch.full((rows, Hp), float("nan")).cuda(),
+                torch.full((rows, Hp), float("nan")).cuda()]
+    L.check(lib.dvae_gru_pointwise_bwd(dh_ref.data_ptr(), Hp, gates.data_ptr(), ghn.data_ptr(), hprev.data_ptr(), Hp,
+                                       outs_ref[0].data_ptr(), outs_ref[1].data_ptr(), outs_ref[2].data_ptr(), Hp, rows,
+                                       Hp, _s()))
+    dh = dh0.clone()
+    outs = [torch.full((rows, 3 * Hp), float("nan")).cuda(), torch.full((rows, Hp), float("nan")).cuda(),
+            torch.full((rows, Hp), float("nan")).cuda()]
+    L.check(lib.dvae_gru_level_bwd(dgm.data_ptr(), K, K, w.data_ptr(), dh.data_ptr(), Hp, gates.data_ptr(),
+                                   ghn.data_ptr(), hprev.data_ptr(), Hp, outs[0].data_ptr(), outs[1].data_ptr(),
+                                   outs[2].data_ptr(), Hp, rows, Hp, _s()))
+    torch.cuda.synchronize()
+    assert (dh - dh_ref).abs().max() < 2e-5
+    for a, b in zip(outs, outs_ref):
+        assert torch.isfinite(a).all() and (a - b).abs().max() < 5e-5
