@@ -1,49 +1,84 @@
-// Level kernels of the state chain (fp32 mode): the hidden product of a level AND its pointwise
-// tail in ONE launch, so the [rows x 3Hp] / [rows x 2Hp] pre-activations never exist in HBM and a
-// level of the forward chain is 2 launches instead of 4.
+// Level kernels of the state chain (fp32 mode): a level's product AND its pointwise tail in ONE
+// launch, so the [rows x 3Hp] / [rows x 2Hp] pre-activations never exist in HBM, a level of the
+// forward chain is 2 launches instead of 4, and the backward products need no split-K atomics.
 //
-//   chain_level_kernel<3>:  (r, z, n, W_hn h + b_hn, h') = GRUCell tail of  h_prev W_hh^T
-//   chain_level_kernel<2>:  (g, m, msg = g*m, next level's predecessor sum) of  h [Wg | Wm]^T
+//   chain_kernel<3, false, 0>:  (r, z, n, W_hn h + b_hn, h') = GRUCell tail of  h_prev W_hh^T
+//   chain_kernel<2, false, 1>:  (g, m, msg = g*m, next level's predecessor sum) of  h [Wg | Wm]^T
+//   chain_kernel<1, true, 2>:   dX += dY W                          (d agg += d gh W_hh)
+//   chain_kernel<1, true, 3>:   d h = dX + dY W, then the GRUCell pointwise backward of d h
 //
-// Why a kernel of its own instead of an epilogue of gemm_f32_kernel: the tail needs the r, z and n
-// (or g and m) pre-activations of one (row, hidden unit) in ONE lane, i.e. columns j, Hp + j,
-// 2Hp + j of the product in one wave.  A workgroup therefore owns 64 rows x 32 hidden units x all
-// NGATE gates (a 64 x 96 or 64 x 64 tile whose B rows come from NGATE row blocks of the weight), and
-// its 4 waves are (K half) x (row half): each wave contracts HALF of every K step for its 32 rows
-// and all gates, the two K halves meet through LDS in the epilogue, and each wave then finishes
-// half of the columns.  At the chain's shape (1024 rows, Hp = 512) that is 256 workgroups = one per
-// CU with all four SIMDs busy for exactly K/2 MFMAs per gate -- where the 64 x 64 tiles of the
-// generic kernel need 1.5 (GRU) rounds of the chip.
+// Why kernels of their own instead of epilogues of gemm_f32_kernel: the forward tails need the r, z
+// and n (or g and m) pre-activations of one (row, hidden unit) in ONE lane, i.e. columns j, Hp + j,
+// 2Hp + j of the product in one wave; and the chain's shape (1024 rows, Hp = 512) is 1.5 rounds of
+// 64 x 64 tiles (GRU) or needs split-K (backward: K = 2Hp / 3Hp, N = Hp).  Here a workgroup owns
+// 64 rows x 32 hidden units x all NGATE gates (B rows from NGATE row blocks of the weight) -> 256
+// workgroups = one per CU at that shape, and its 8 waves are (K quarter) x (row half): every wave
+// contracts a quarter of each 64-deep K step for its 32 rows and all gates, so each SIMD holds two
+// waves whose MFMA streams fill each other's waits (a lone wave per SIMD ran the same loop at 60 %
+// of the MFMA rate).  The four K quarters meet through LDS in the epilogue and each wave finishes
+// one register quad (8 columns x 32 rows as 16-byte accesses).  Deterministic: no atomics, fixed
+// summation order.
 //
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32), accumulated transposed (operands swapped) so a lane
-// ends up with 4 consecutive hidden units of one row per register quad -> 16-byte loads / stores in
-// the tail.  LDS images as in gemm.hip: [rows][36] floats, ds_read_b128 fragments, two stages,
-// register-staged global loads one tile ahead, one barrier per K step.
+// holds 4 consecutive hidden units of one row per register quad.  LDS images as in gemm.hip:
+// K-contiguous operands [rows][68] floats read with ds_read_b128, the K-major weight of the
+// backward products [64 k][40] read with ds_read_b32; two stages, register-staged global loads,
+// one barrier per K step.
 #include "gemm_common.h"
 
 namespace dvae {
 
 constexpr int CBM = 64;        // rows per workgroup
-constexpr int CBH = 32;        // hidden units per workgroup (times NGATE product columns)
-constexpr int CBK = 32;        // K step
-constexpr int CLD = CBK + 4;   // LDS row stride (floats)
+constexpr int CBH = 32;        // hidden units (output columns per gate) per workgroup
+constexpr int CBK = 64;        // K step: four quarters of 16, one per wave pair
+constexpr int CLD = CBK + 4;   // LDS row stride of a K-contiguous image (floats)
+constexpr int CLW = 40;        // LDS row stride of the K-major W image [64 k][32 cols]: lane halves 4 k rows apart hit disjoint banks
+constexpr int CNT = 512;       // threads per workgroup
 
 struct ChainParams {
-    const float* A; int lda;   // [M][K] states (h_prev / h of the level)
-    const float* W; int ldw;   // [NGATE * Hp][K] weight, K contiguous
+    const float* A; int lda;   // [M][K] K-contiguous operand (states, or dY of the backward products)
+    const float* W; int ldw;   // forward: [NGATE * Hp][K] K-contiguous;  backward: [K][Hp]
     int M, Hp, K;
     int tiles_x, tiles_y;      // Hp / 32, ceil(M / 64)
-    // GRU tail
+    // GRU tail (gates / ghn are outputs of the forward tail, inputs of the backward one)
     const float* gi_tab; const int* types; const float* bhn; const float* hprev; int ld_hprev;
     float* gates; float* ghn; float* hout; int ld_hout;
     // gate / mapper tail
     const float* gv; float* gm; float* msg; int ld_msg; int cur_row0;
     float* next_agg; int ld_agg; const int* next_off; const int* idx;
+    // backward: dX in/out and the outputs of the GRU backward tail
+    float* C; int ldc;
+    float* dgh; float* dgin; float* dhprev; int ld_dhprev;
 };
 
 __device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void cst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <int V>
+struct IC { static constexpr int value = V; };  // compile-time register-set index for the staging lambdas
+// steps t .. t+PF-1 of a K loop whose step count is a multiple of PF: the register set of tile
+// t+j+1 is the constant (j+1) % PF (t % PF == 0), and there is NO branch between the steps -- with
+// conditional loads hipcc's wait-count insertion falls back to s_waitcnt vmcnt(0) before every
+// LDS store, which drains all the tiles in flight.
+template <int J, int PF, class F>
+__device__ __forceinline__ void steps_unrolled(F& step, int t) {
+    if constexpr (J < PF) {
+        step(IC<(J + 1) % PF>{}, t + J);
+        steps_unrolled<J + 1, PF>(step, t);
+    }
+}
+// prologue: tiles 1 .. PF-1 -> sets 1 .. PF-1
+template <int J, int PF, class F>
+__device__ __forceinline__ void prefetch_unrolled(F& gload) {
+    if constexpr (J < PF) {
+        gload(IC<J>{}, J);
+        prefetch_unrolled<J + 1, PF>(gload);
+    }
+}
+#ifndef CHAIN_PF
+#define CHAIN_PF 2  // register-staged tiles in flight in the unrolled kernels (1, 2, 4 or 8; measured: no effect beyond 1)
+#endif
 
+// ---------------------------------------------------------------------------------- tails
 // GRUCell tail for 4 consecutive hidden units of one row (same arithmetic as gru_fwd_kernel)
 __device__ __forceinline__ void gru_tail(const ChainParams& p, int row, int col, float4 ghr, float4 ghz, float4 ghn) {
     const float* gi = p.gi_tab + (long)p.types[row] * 3 * p.Hp;
@@ -94,177 +129,8 @@ __device__ __forceinline__ void gate_tail(const ChainParams& p, int row, int col
     }
 }
 
-// Epilogue of the wave with K half KH: hand the partner wave (other K half, same rows) the two
-// register quads it finishes, take its partial sums of quads 2KH, 2KH+1, run the tail on them.
-template <int NGATE, int KH>
-__device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&acc)[NGATE], float* lds, int m0, int n0,
-                                               int wm, int lane) {
-    float4* xch = reinterpret_cast<float4*>(lds);
-    constexpr int MINE = 2 * KH, THEIRS = 2 * (1 - KH);
-#pragma unroll
-    for (int i = 0; i < NGATE; ++i)
-#pragma unroll
-        for (int ql = 0; ql < 2; ++ql) {
-            const int q = THEIRS + ql;
-            xch[(((KH * 2 + wm) * NGATE + i) * 2 + ql) * 64 + lane] =
-                make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
-        }
-    __syncthreads();
-    const int row = m0 + wm * 32 + (lane & 31), h = lane >> 5;
-    float4 v[NGATE][2];
-#pragma unroll
-    for (int i = 0; i < NGATE; ++i)
-#pragma unroll
-        for (int ql = 0; ql < 2; ++ql) {
-            const int q = MINE + ql;
-            const float4 o = xch[((((1 - KH) * 2 + wm) * NGATE + i) * 2 + ql) * 64 + lane];
-            // (K half 0) + (K half 1): fp32 addition commutes, so both waves form the same sum
-            v[i][ql] = make_float4(acc[i][4 * q] + o.x, acc[i][4 * q + 1] + o.y, acc[i][4 * q + 2] + o.z,
-                                   acc[i][4 * q + 3] + o.w);
-        }
-    if (row >= p.M) return;
-#pragma unroll
-    for (int ql = 0; ql < 2; ++ql) {
-        const int col = n0 + 8 * (MINE + ql) + 4 * h;
-        if (NGATE == 3) gru_tail(p, row, col, v[0][ql], v[1][ql], v[NGATE - 1][ql]);
-        else gate_tail(p, row, col, v[0][ql], v[1][ql]);
-    }
-}
-
-template <int NGATE>
-__global__ __launch_bounds__(256) void chain_level_kernel(ChainParams p) {
-    constexpr int STAGE = (CBM + NGATE * 32) * CLD;  // A image then the NGATE weight images
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-    static_assert(2 * STAGE * 4 >= 4 * NGATE * 2 * 64 * 16, "the K-half exchange reuses the stage buffers");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kh = wave >> 1, wm = wave & 1;
-    int m0, n0;
-    tile_origin<CBM, CBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
-
-    // register-staged loaders: thread -> row tid/8 (+32 for the second A unit / per gate), 16 bytes at (tid%8)*4
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
-    const float *pa0, *pa1, *pw0, *pw1, *pw2;
-    {
-        int r = m0 + lr;
-        r = r < p.M ? r : p.M - 1;  // clamped rows are computed but never stored
-        pa0 = p.A + (long)r * p.lda + lc;
-        r = m0 + lr + 32;
-        r = r < p.M ? r : p.M - 1;
-        pa1 = p.A + (long)r * p.lda + lc;
-        pw0 = p.W + (long)(n0 + lr) * p.ldw + lc;
-        pw1 = pw0 + (long)p.Hp * p.ldw;
-        pw2 = pw1 + (long)p.Hp * p.ldw;
-    }
-    const int so = lr * CLD + lc;
-    float4 ra0, ra1, rw0, rw1, rw2;
-    auto gload = [&](int k0) {
-        ra0 = cld4(pa0 + k0);
-        ra1 = cld4(pa1 + k0);
-        rw0 = cld4(pw0 + k0);
-        rw1 = cld4(pw1 + k0);
-        if (NGATE == 3) rw2 = cld4(pw2 + k0);
-    };
-    auto lstore = [&](float* st) {
-        cst4(st + so, ra0);
-        cst4(st + so + 32 * CLD, ra1);
-        cst4(st + so + CBM * CLD, rw0);
-        cst4(st + so + (CBM + 32) * CLD, rw1);
-        if (NGATE == 3) cst4(st + so + (CBM + 64) * CLD, rw2);
-    };
-
-    f32x16 acc[NGATE];
-#pragma unroll
-    for (int i = 0; i < NGATE; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    const int nk = p.K / CBK;
-    gload(0);
-    lstore(lds);
-    if (nk > 1) gload(CBK);
-    __syncthreads();
-    // fragment base of this wave: row (lane & 31) of its row half / of each gate image, k offset of
-    // its K half (groups 2kh, 2kh+1 of 8 k each) and lane half
-    const int fo = (lane & 31) * CLD + kh * 16 + 4 * (lane >> 5);
-    for (int t = 0; t < nk; ++t) {
-        const float* cs = lds + (t & 1) * STAGE;
-        float* ns = lds + ((t & 1) ^ 1) * STAGE;
-        float4 fa[2], fw[2][NGATE];
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            fa[gg] = cld4(cs + wm * 32 * CLD + fo + gg * 8);
-#pragma unroll
-            for (int i = 0; i < NGATE; ++i) fw[gg][i] = cld4(cs + (CBM + i * 32) * CLD + fo + gg * 8);
-        }
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-#pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].x, fa[gg].x, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].y, fa[gg].y, acc[i], 0, 0, 0);
-            if (gg == 0 && t + 1 < nk) {
-                // tile t+1 (in flight since the previous step): registers -> the other stage; reload from tile t+2
-                lstore(ns);
-                if (t + 2 < nk) gload((t + 2) * CBK);
-            }
-#pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].z, fa[gg].z, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].w, fa[gg].w, acc[i], 0, 0, 0);
-        }
-        __syncthreads();  // stage t^1 complete; every wave holds its fragments of stage t in registers
-    }
-    if (kh == 0) chain_epilogue<NGATE, 0>(p, acc, lds, m0, n0, wm, lane);
-    else chain_epilogue<NGATE, 1>(p, acc, lds, m0, n0, wm, lane);
-}
-
-static int chain_check(const float* A, int lda, const float* W, int rows, int Hp) {
-    DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
-    DVAE_REQUIRE(A && W, "chain level: null operand");
-    DVAE_REQUIRE(lda >= Hp && lda % 4 == 0, "chain level: bad leading dimension %d", lda);
-    DVAE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "chain level: operands must be 16-byte aligned");
-    return DVAE_OK;
-}
-
-template <int NGATE>
-static int chain_launch(ChainParams& p, hipStream_t s) {
-    p.K = p.Hp;
-    p.ldw = p.Hp;
-    p.tiles_x = p.Hp / CBH;
-    p.tiles_y = cdiv(p.M, CBM);
-    hipLaunchKernelGGL((chain_level_kernel<NGATE>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, s, p);
-    DVAE_LAUNCH_CHECK();
-    return DVAE_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Backward twin: the input gradient of a level's product, dX[M x Hp] += dY[M x K] W[K x Hp]
-// (W = the nn.Linear weight [out = K][in = Hp], i.e. K-major for this contraction), with the same
-// balance -- 64 rows x 32 columns per workgroup, the two wave pairs each contract half of every
-// 64-deep K step, so M = 1024, Hp = 512 is again 256 workgroups with all four SIMDs busy -- where
-// the generic kernel runs these K = 2Hp / 3Hp, N = Hp products as split-K with fp32 atomics.
-//   TAIL 0: dX += product                                   (d agg += d gh W_hh)
-//   TAIL 1: d h = dX + product, then the GRUCell pointwise backward of d h in the same launch
-//           (d h += d gm [Wg | Wm]; gru_bwd_kernel's arithmetic)
-// The result is deterministic (no atomics).
-constexpr int DBK = 64;        // K step (two halves of 32)
-constexpr int DLA = DBK + 4;   // LDS row stride of the dY image [64 rows][64 k]
-constexpr int DLW = 40;        // LDS row stride of the W image [64 k][32 cols]: lane halves 4 k rows apart hit disjoint banks
-
-struct ChainBwdParams {
-    const float* A; int lda;   // dY [M][K]
-    const float* W; int ldw;   // [K][Hp]
-    float* C; int ldc;         // dX [M][Hp], read and written
-    int M, Hp, K;
-    int tiles_x, tiles_y;
-    // GRU backward tail
-    const float* gates; const float* ghn; const float* hprev; int ld_hprev;
-    float* dgh; float* dgin; float* dhprev; int ld_dhprev;
-};
-
-// same arithmetic as gru_bwd_kernel for 4 consecutive hidden units of one row
-__device__ __forceinline__ void gru_bwd_tail(const ChainBwdParams& p, int row, int col, float4 D) {
+// GRUCell pointwise backward for 4 consecutive hidden units of one row (gru_bwd_kernel's arithmetic)
+__device__ __forceinline__ void gru_bwd_tail(const ChainParams& p, int row, int col, float4 D) {
     const float* g = p.gates + (long)row * 3 * p.Hp;
     const float4 R = cld4(g + col), Z = cld4(g + p.Hp + col), N = cld4(g + 2 * p.Hp + col);
     const float4 GN = cld4(p.ghn + (long)row * p.Hp + col);
@@ -293,140 +159,229 @@ __device__ __forceinline__ void gru_bwd_tail(const ChainBwdParams& p, int row, i
     cst4(p.dhprev + (long)row * p.ld_dhprev + col, dHP);
 }
 
-template <int TAIL, int KH>
-__device__ __forceinline__ void chain_bwd_epilogue(const ChainBwdParams& p, f32x16& acc, float* lds, int m0, int n0,
-                                                   int wm, int lane) {
+// ---------------------------------------------------------------------------------- epilogue
+// TAIL: 0 GRU forward (NGATE 3), 1 gate/mapper forward (NGATE 2), 2 dX += (NGATE 1), 3 dX += then GRU backward.
+// The wave of K quarter KQ finishes register quad KQ (columns 8 KQ + 4 (lane / 32) .. + 3): it
+// hands the other three quads to their owners through LDS, adds the three partial sums it
+// receives and its own IN K ORDER, and runs the tail.
+template <int NGATE, int TAIL, int KQ>
+__device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&acc)[NGATE], float* lds, int m0, int n0,
+                                               int wm, int lane) {
     float4* xch = reinterpret_cast<float4*>(lds);
-    constexpr int MINE = 2 * KH, THEIRS = 2 * (1 - KH);
+    // slot of (destination quad q, source quarter k != q): ((q * 3 + (k < q ? k : k - 1)) * 2 + wm) * NGATE + gate
 #pragma unroll
-    for (int ql = 0; ql < 2; ++ql) {
-        const int q = THEIRS + ql;
-        xch[((KH * 2 + wm) * 2 + ql) * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) {
+        if (q == KQ) continue;
+        const int src = KQ < q ? KQ : KQ - 1;
+#pragma unroll
+        for (int i = 0; i < NGATE; ++i)
+            xch[(((q * 3 + src) * 2 + wm) * NGATE + i) * 64 + lane] =
+                make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
     }
     __syncthreads();
     const int row = m0 + wm * 32 + (lane & 31), h = lane >> 5;
-    if (row >= p.M) return;
+    float4 v[NGATE];
 #pragma unroll
-    for (int ql = 0; ql < 2; ++ql) {
-        const int q = MINE + ql;
-        const float4 o = xch[(((1 - KH) * 2 + wm) * 2 + ql) * 64 + lane];
-        const int col = n0 + 8 * q + 4 * h;
+    for (int i = 0; i < NGATE; ++i) {
+        const float4 own = make_float4(acc[i][4 * KQ], acc[i][4 * KQ + 1], acc[i][4 * KQ + 2], acc[i][4 * KQ + 3]);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // K quarters 0, 1, 2, 3 in order
+            float4 t;
+            if (k == KQ) t = own;
+            else t = xch[(((KQ * 3 + (k < KQ ? k : k - 1)) * 2 + wm) * NGATE + i) * 64 + lane];
+            if (k == 0) s = t;
+            else { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        }
+        v[i] = s;
+    }
+    if (row >= p.M) return;
+    const int col = n0 + 8 * KQ + 4 * h;
+    if (TAIL == 0) {
+        gru_tail(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
+    } else if (TAIL == 1) {
+        gate_tail(p, row, col, v[0], v[NGATE - 1]);
+    } else {
         float* c = p.C + (long)row * p.ldc + col;
         const float4 c0 = cld4(c);
-        // (K half 0 + K half 1) + dX: the same value whichever wave forms it
-        const float4 v = make_float4(c0.x + (acc[4 * q] + o.x), c0.y + (acc[4 * q + 1] + o.y), c0.z + (acc[4 * q + 2] + o.z),
-                                     c0.w + (acc[4 * q + 3] + o.w));
-        cst4(c, v);
-        if (TAIL == 1) gru_bwd_tail(p, row, col, v);
+        const float4 d = make_float4(c0.x + v[0].x, c0.y + v[0].y, c0.z + v[0].z, c0.w + v[0].w);
+        cst4(c, d);
+        if (TAIL == 3) gru_bwd_tail(p, row, col, d);
     }
 }
 
-template <int TAIL>
-__global__ __launch_bounds__(256) void chain_dgrad_kernel(ChainBwdParams p) {
-    constexpr int STAGE = CBM * DLA + DBK * DLW;  // dY image then W image
+// ---------------------------------------------------------------------------------- kernel
+// NK > 0: the number of K steps, known at compile time -- the K loop is then unrolled completely
+// (around a loop back-edge hipcc rotates the staging registers with moves that wait for every
+// outstanding load, s_waitcnt vmcnt(0) once per trip).  NK == 0: any K, runtime loop, PF = 1.
+// K % 64 may be 32: the second half of the last step then lies past K; its loads are redirected
+// to valid addresses and the A half is stored to LDS as zeros (the weight half stays finite).
+//
+// WKM = false: forward product, W [NGATE * Hp][K] K-contiguous (TAIL 0 / 1)
+// WKM = true:  backward product, W [K][Hp] (NGATE = 1, TAIL 2 / 3)
+template <int NGATE, bool WKM, int TAIL, int PF, int NK>
+__global__ __launch_bounds__(CNT) void chain_kernel(ChainParams p) {
+    constexpr int A_ELEMS = CBM * CLD;
+    constexpr int W_ELEMS = WKM ? CBK * CLW : NGATE * 32 * CLD;
+    constexpr int STAGE = A_ELEMS + W_ELEMS;
+    constexpr int WU = WKM ? 1 : NGATE;  // weight staging units (16 bytes) per thread; the A operand has 2
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    static_assert(2 * STAGE * 4 >= 4 * 3 * 2 * NGATE * 64 * 16, "the K-quarter exchange reuses the stage buffers");
+    static_assert(NK % PF == 0 && (NK > 0 || PF == 1), "PF must divide the step count");
+    static_assert(!WKM || NGATE == 1, "backward products have one output block per wave");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kh = wave >> 1, wm = wave & 1;
+    const int kq = wave >> 1, wm = wave & 1;
     int m0, n0;
     tile_origin<CBM, CBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
 
-    // dY: thread -> rows tid/16 + 16 i (i = 0..3), 16 bytes at k (tid%16)*4;  W: k rows tid/8 + 32 i, cols (tid%8)*4
+    // A: thread -> rows tid/16 and tid/16 + 32, 16 bytes at k (tid%16)*4
+    // W K-contiguous: rows tid/16 of each gate block, the same k;  W K-major: k row tid/8, columns (tid%8)*4
     const int ar = tid >> 4, ak = (tid & 15) * 4;
-    const int wk = tid >> 3, wc = (tid & 7) * 4;
-    const float *pa0, *pa1, *pa2, *pa3;
+    const float *pa0, *pa1, *pw0, *pw1, *pw2;
     {
-        auto rowp = [&](int i) {
-            int r = m0 + ar + 16 * i;
-            r = r < p.M ? r : p.M - 1;  // clamped rows are computed but never stored
-            return p.A + (long)r * p.lda;
-        };
-        pa0 = rowp(0); pa1 = rowp(1); pa2 = rowp(2); pa3 = rowp(3);
+        int r = m0 + ar;
+        r = r < p.M ? r : p.M - 1;  // clamped rows are computed but never stored
+        pa0 = p.A + (long)r * p.lda;
+        r = m0 + ar + 32;
+        r = r < p.M ? r : p.M - 1;
+        pa1 = p.A + (long)r * p.lda;
+        if (!WKM) {
+            pw0 = p.W + (long)(n0 + ar) * p.ldw;
+            pw1 = pw0 + (long)p.Hp * p.ldw;
+            pw2 = pw1 + (long)p.Hp * p.ldw;
+        } else {
+            pw0 = p.W + n0 + (tid & 7) * 4;
+            pw1 = pw2 = pw0;
+        }
     }
-    const float* pwc = p.W + n0 + wc;
-    const int sa = ar * DLA + ak, sw = CBM * DLA + wk * DLW + wc;
-    float4 ra0, ra1, ra2, ra3, rw0, rw1;
-    // K % 64 may be 32: the second half of the last step then lies past K; its loads are redirected
-    // to valid addresses and the K-half-1 waves skip that half (below)
-    auto gload = [&](int k0) {
+    const int sa = ar * CLD + ak;
+    const int sw = A_ELEMS + (WKM ? (tid >> 3) * CLW + (tid & 7) * 4 : ar * CLD + ak);
+    const int nk = NK > 0 ? NK : (p.K + CBK - 1) / CBK;
+    float4 rs[PF][2 + WU];
+    auto gload = [&](auto S, int tile) {  // tiles past the end reload the last one (never used)
+        constexpr int s_ = decltype(S)::value;
+        const int k0 = (tile < nk ? tile : nk - 1) * CBK;
         int ka = k0 + ak;
         ka = ka < p.K ? ka : ka - 32;
-        ra0 = cld4(pa0 + ka);
-        ra1 = cld4(pa1 + ka);
-        ra2 = cld4(pa2 + ka);
-        ra3 = cld4(pa3 + ka);
-        const int k1 = k0 + wk + 32;
-        rw0 = cld4(pwc + (long)(k0 + wk) * p.ldw);
-        rw1 = cld4(pwc + (long)(k1 < p.K ? k1 : k1 - 32) * p.ldw);
+        rs[s_][0] = cld4(pa0 + ka);
+        rs[s_][1] = cld4(pa1 + ka);
+        if (!WKM) {
+            rs[s_][2] = cld4(pw0 + ka);
+            if (NGATE > 1) rs[s_][WU > 1 ? 3 : 2] = cld4(pw1 + ka);
+            if (NGATE > 2) rs[s_][WU > 2 ? 4 : 2] = cld4(pw2 + ka);
+        } else {
+            int kw = k0 + (tid >> 3);
+            kw = kw < p.K ? kw : kw - 32;
+            rs[s_][2] = cld4(pw0 + (long)kw * p.ldw);
+        }
     };
-    auto lstore = [&](float* st) {
-        cst4(st + sa, ra0);
-        cst4(st + sa + 16 * DLA, ra1);
-        cst4(st + sa + 32 * DLA, ra2);
-        cst4(st + sa + 48 * DLA, ra3);
-        cst4(st + sw, rw0);
-        cst4(st + sw + 32 * DLW, rw1);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto lstore = [&](auto S, float* st, int tile) {
+        constexpr int s_ = decltype(S)::value;
+        const bool past = tile * CBK + ak >= p.K;  // only in the last step of a K with K % 64 == 32
+        cst4(st + sa, past ? zero4 : rs[s_][0]);
+        cst4(st + sa + 32 * CLD, past ? zero4 : rs[s_][1]);
+        cst4(st + sw, rs[s_][2]);
+        if (!WKM && NGATE > 1) cst4(st + sw + 32 * CLD, rs[s_][WU > 1 ? 3 : 2]);
+        if (!WKM && NGATE > 2) cst4(st + sw + 64 * CLD, rs[s_][WU > 2 ? 4 : 2]);
     };
 
-    f32x16 acc;
+    f32x16 acc[NGATE];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < NGATE; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int nk = (p.K + DBK - 1) / DBK;
-    gload(0);
-    lstore(lds);
-    if (nk > 1) gload(DBK);
+    // tiles 0 .. PF-1 -> sets 0 .. PF-1, tile 0 -> LDS, tile PF -> set 0
+    gload(IC<0>{}, 0);
+    prefetch_unrolled<1, PF>(gload);
+    lstore(IC<0>{}, lds, 0);
+    gload(IC<0>{}, PF);
     __syncthreads();
-    const int foa = (wm * 32 + (lane & 31)) * DLA + kh * 32 + 4 * (lane >> 5);
-    const int fow = CBM * DLA + (kh * 32 + 4 * (lane >> 5)) * DLW + (lane & 31);
-    for (int t = 0; t < nk; ++t) {
+    // fragment bases of this wave: row (lane & 31) of its row half / of each gate image (or column
+    // lane & 31 of the K-major image), k offset of its K quarter (2 groups of 8 k) and lane half
+    const int foa = (wm * 32 + (lane & 31)) * CLD + kq * 16 + 4 * (lane >> 5);
+    const int fow = A_ELEMS + (WKM ? (kq * 16 + 4 * (lane >> 5)) * CLW + (lane & 31)
+                                   : (lane & 31) * CLD + kq * 16 + 4 * (lane >> 5));
+    // step t computes tile t from stage t & 1; tile t+1 sits in register set (t+1) % PF
+    auto step = [&](auto S, int t) {
         const float* cs = lds + (t & 1) * STAGE;
         float* ns = lds + ((t & 1) ^ 1) * STAGE;
-        const bool active = t * DBK + kh * 32 < p.K;  // wave-uniform
-        float4 fa[4], fw[4];
+        float4 fa[2], fw[2][NGATE];
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
+        for (int gg = 0; gg < 2; ++gg) {
             fa[gg] = cld4(cs + foa + gg * 8);
-            const float* w = cs + fow + gg * 8 * DLW;
-            fw[gg] = make_float4(w[0], w[DLW], w[2 * DLW], w[3 * DLW]);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) {
+                if (!WKM) {
+                    fw[gg][i] = cld4(cs + fow + i * 32 * CLD + gg * 8);
+                } else {
+                    const float* w = cs + fow + gg * 8 * CLW;
+                    fw[gg][i] = make_float4(w[0], w[CLW], w[2 * CLW], w[3 * CLW]);
+                }
+            }
         }
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            if (active) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg].x, fa[gg].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg].y, fa[gg].y, acc, 0, 0, 0);
+        for (int gg = 0; gg < 2; ++gg) {
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].x, fa[gg].x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].y, fa[gg].y, acc[i], 0, 0, 0);
+            if (gg == 0) {
+                // tile t+1 (in flight for PF steps): registers -> the other stage; reload from tile t+1+PF
+                lstore(S, ns, t + 1);
+                gload(S, t + 1 + PF);
             }
-            if (gg == 0 && t + 1 < nk) {
-                lstore(ns);
-                if (t + 2 < nk) gload((t + 2) * DBK);
-            }
-            if (active) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg].z, fa[gg].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg].w, fa[gg].w, acc, 0, 0, 0);
-            }
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].z, fa[gg].z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].w, fa[gg].w, acc[i], 0, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();  // stage t^1 complete; every wave holds its fragments of stage t in registers
+    };
+    if constexpr (NK > 0) {
+#pragma unroll
+        for (int t = 0; t < NK; t += PF) steps_unrolled<0, PF>(step, t);  // t % PF == 0: set indices are constants
+    } else {
+        for (int t = 0; t < nk; ++t) step(IC<0>{}, t);
     }
-    if (kh == 0) chain_bwd_epilogue<TAIL, 0>(p, acc, lds, m0, n0, wm, lane);
-    else chain_bwd_epilogue<TAIL, 1>(p, acc, lds, m0, n0, wm, lane);
+    // (wave-uniform switch: the quad a wave finishes must be a compile-time register index)
+    switch (kq) {
+    case 0: chain_epilogue<NGATE, TAIL, 0>(p, acc, lds, m0, n0, wm, lane); break;
+    case 1: chain_epilogue<NGATE, TAIL, 1>(p, acc, lds, m0, n0, wm, lane); break;
+    case 2: chain_epilogue<NGATE, TAIL, 2>(p, acc, lds, m0, n0, wm, lane); break;
+    default: chain_epilogue<NGATE, TAIL, 3>(p, acc, lds, m0, n0, wm, lane); break;
+    }
 }
 
-template <int TAIL>
-static int chain_bwd_launch(ChainBwdParams& p, hipStream_t s) {
-    p.ldw = p.Hp;
+// ---------------------------------------------------------------------------------- host
+template <int NGATE, bool WKM, int TAIL>
+static int chain_launch(ChainParams& p, hipStream_t s) {
     p.tiles_x = p.Hp / CBH;
     p.tiles_y = cdiv(p.M, CBM);
-    hipLaunchKernelGGL((chain_dgrad_kernel<TAIL>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(CNT);
+#define CHAIN_CASE(NK_) \
+    case NK_: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, CHAIN_PF, NK_>), grid, block, 0, s, p); break;
+    // K = Hp (forward) and 2Hp / 3Hp (backward) for Hp = 512 (hs 501) and 1024 get the unrolled K loop
+    switch (p.K % CBK == 0 ? p.K / CBK : 0) {
+        CHAIN_CASE(8)
+        CHAIN_CASE(16)
+        CHAIN_CASE(24)
+        CHAIN_CASE(32)
+        CHAIN_CASE(48)
+    default: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, 1, 0>), grid, block, 0, s, p); break;
+    }
+#undef CHAIN_CASE
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
 
-static int chain_bwd_check(const float* dy, int ld_dy, int K, const float* w, const float* dx, int ld_dx, int rows, int Hp) {
-    DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "level dgrad: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
-    DVAE_REQUIRE(K >= 32 && K % 32 == 0, "level dgrad: K must be a positive multiple of 32 (K=%d)", K);
-    DVAE_REQUIRE(dy && w && dx, "level dgrad: null operand");
-    DVAE_REQUIRE(ld_dy >= K && ld_dy % 4 == 0 && ld_dx >= Hp && ld_dx % 4 == 0, "level dgrad: bad leading dimension");
-    DVAE_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)dx % 16) == 0,
-                 "level dgrad: operands must be 16-byte aligned");
+static int chain_check(const float* A, int lda, int K, const float* W, int rows, int Hp) {
+    DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
+    DVAE_REQUIRE(K >= 32 && K % 32 == 0, "chain level: K must be a positive multiple of 32 (K=%d)", K);
+    DVAE_REQUIRE(A && W, "chain level: null operand");
+    DVAE_REQUIRE(lda >= K && lda % 4 == 0, "chain level: bad leading dimension %d", lda);
+    DVAE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "chain level: operands must be 16-byte aligned");
     return DVAE_OK;
 }
 
@@ -438,17 +393,17 @@ extern "C" int dvae_gru_level_fwd(const float* hprev, int32_t ld_hprev, const fl
                                   const int32_t* types, const float* bhn, float* gates, float* ghn_out, float* hout,
                                   int32_t ld_hout, int32_t rows, int32_t Hp, void* stream) {
     if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(hprev, ld_hprev, whh, rows, Hp));
+    DVAE_TRY(chain_check(hprev, ld_hprev, Hp, whh, rows, Hp));
     DVAE_REQUIRE(gi_tab && types && bhn && gates && ghn_out && hout, "gru_level_fwd: null pointer");
     DVAE_REQUIRE(ld_hout >= Hp && ld_hout % 4 == 0, "gru_level_fwd: bad ld_hout %d", ld_hout);
     DVAE_REQUIRE(((uintptr_t)gi_tab % 16) == 0 && ((uintptr_t)bhn % 16) == 0 && ((uintptr_t)gates % 16) == 0 &&
                      ((uintptr_t)ghn_out % 16) == 0 && ((uintptr_t)hout % 16) == 0,
                  "gru_level_fwd: buffers must be 16-byte aligned");
     ChainParams p = {};
-    p.A = hprev; p.lda = ld_hprev; p.W = whh; p.M = rows; p.Hp = Hp;
+    p.A = hprev; p.lda = ld_hprev; p.W = whh; p.ldw = Hp; p.M = rows; p.Hp = Hp; p.K = Hp;
     p.gi_tab = gi_tab; p.types = types; p.bhn = bhn; p.hprev = hprev; p.ld_hprev = ld_hprev;
     p.gates = gates; p.ghn = ghn_out; p.hout = hout; p.ld_hout = ld_hout;
-    return chain_launch<3>(p, (hipStream_t)stream);
+    return chain_launch<3, false, 0>(p, (hipStream_t)stream);
 }
 
 extern "C" int dvae_gated_level_fwd(const float* h, int32_t ld_h, const float* wgm, const float* gv_row, float* gm,
@@ -456,7 +411,7 @@ extern "C" int dvae_gated_level_fwd(const float* h, int32_t ld_h, const float* w
                                     const int32_t* next_off, const int32_t* idx, int32_t rows, int32_t Hp,
                                     void* stream) {
     if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(h, ld_h, wgm, rows, Hp));
+    DVAE_TRY(chain_check(h, ld_h, Hp, wgm, rows, Hp));
     DVAE_REQUIRE(gv_row && gm && msg, "gated_level_fwd: null pointer");
     DVAE_REQUIRE(!next_agg || (next_off && idx), "gated_level_fwd: next_agg needs the CSR lists");
     DVAE_REQUIRE(ld_msg >= Hp && ld_msg % 4 == 0 && (!next_agg || (ld_agg >= Hp && ld_agg % 4 == 0)),
@@ -465,19 +420,20 @@ extern "C" int dvae_gated_level_fwd(const float* h, int32_t ld_h, const float* w
                      ((uintptr_t)next_agg % 16) == 0,
                  "gated_level_fwd: buffers must be 16-byte aligned");
     ChainParams p = {};
-    p.A = h; p.lda = ld_h; p.W = wgm; p.M = rows; p.Hp = Hp;
+    p.A = h; p.lda = ld_h; p.W = wgm; p.ldw = Hp; p.M = rows; p.Hp = Hp; p.K = Hp;
     p.gv = gv_row; p.gm = gm; p.msg = msg; p.ld_msg = ld_msg; p.cur_row0 = cur_row0;
     p.next_agg = next_agg; p.ld_agg = ld_agg; p.next_off = next_off; p.idx = idx;
-    return chain_launch<2>(p, (hipStream_t)stream);
+    return chain_launch<2, false, 1>(p, (hipStream_t)stream);
 }
 
 extern "C" int dvae_level_dgrad_acc(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dx, int32_t ld_dx,
                                     int32_t rows, int32_t Hp, void* stream) {
     if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_bwd_check(dy, ld_dy, K, w, dx, ld_dx, rows, Hp));
-    ChainBwdParams p = {};
-    p.A = dy; p.lda = ld_dy; p.W = w; p.C = dx; p.ldc = ld_dx; p.M = rows; p.Hp = Hp; p.K = K;
-    return chain_bwd_launch<0>(p, (hipStream_t)stream);
+    DVAE_TRY(chain_check(dy, ld_dy, K, w, rows, Hp));
+    DVAE_REQUIRE(dx && ld_dx >= Hp && ld_dx % 4 == 0 && ((uintptr_t)dx % 16) == 0, "level_dgrad_acc: bad dx / ld_dx");
+    ChainParams p = {};
+    p.A = dy; p.lda = ld_dy; p.W = w; p.ldw = Hp; p.C = dx; p.ldc = ld_dx; p.M = rows; p.Hp = Hp; p.K = K;
+    return chain_launch<1, true, 2>(p, (hipStream_t)stream);
 }
 
 extern "C" int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dh, int32_t ld_dh,
@@ -485,16 +441,17 @@ extern "C" int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, con
                                   float* dgh, float* dgin, float* dhprev, int32_t ld_dhprev, int32_t rows, int32_t Hp,
                                   void* stream) {
     if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_bwd_check(dy, ld_dy, K, w, dh, ld_dh, rows, Hp));
+    DVAE_TRY(chain_check(dy, ld_dy, K, w, rows, Hp));
+    DVAE_REQUIRE(dh && ld_dh >= Hp && ld_dh % 4 == 0 && ((uintptr_t)dh % 16) == 0, "gru_level_bwd: bad dh / ld_dh");
     DVAE_REQUIRE(gates && ghn && hprev && dgh && dgin && dhprev, "gru_level_bwd: null pointer");
     DVAE_REQUIRE(ld_hprev >= Hp && ld_hprev % 4 == 0 && ld_dhprev >= Hp && ld_dhprev % 4 == 0,
                  "gru_level_bwd: bad leading dimension");
     DVAE_REQUIRE(((uintptr_t)gates % 16) == 0 && ((uintptr_t)ghn % 16) == 0 && ((uintptr_t)hprev % 16) == 0 &&
                      ((uintptr_t)dgh % 16) == 0 && ((uintptr_t)dgin % 16) == 0 && ((uintptr_t)dhprev % 16) == 0,
                  "gru_level_bwd: buffers must be 16-byte aligned");
-    ChainBwdParams p = {};
-    p.A = dy; p.lda = ld_dy; p.W = w; p.C = dh; p.ldc = ld_dh; p.M = rows; p.Hp = Hp; p.K = K;
-    p.gates = gates; p.ghn = ghn; p.hprev = hprev; p.ld_hprev = ld_hprev;
+    ChainParams p = {};
+    p.A = dy; p.lda = ld_dy; p.W = w; p.ldw = Hp; p.C = dh; p.ldc = ld_dh; p.M = rows; p.Hp = Hp; p.K = K;
+    p.gates = const_cast<float*>(gates); p.ghn = const_cast<float*>(ghn); p.hprev = hprev; p.ld_hprev = ld_hprev;
     p.dgh = dgh; p.dgin = dgin; p.dhprev = dhprev; p.ld_dhprev = ld_dhprev;
-    return chain_bwd_launch<1>(p, (hipStream_t)stream);
+    return chain_launch<1, true, 3>(p, (hipStream_t)stream);
 }

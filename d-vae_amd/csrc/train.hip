@@ -275,9 +275,9 @@ static bool chain_fused(const Dims& d) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
     return knob != 0 && !d.bf16 && !d.bn;
 }
-// the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD
+// the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD=0 falls back
 static bool chain_fused_bwd(const Dims& d) {
-    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 0; }();
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
     return knob != 0 && !d.bf16 && !d.bn;
 }
 

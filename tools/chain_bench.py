@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _dvae_pkg import dvae_amd  # noqa: E402
 
 L = dvae_amd._lib
+if os.environ.get("DVAE_EXP_LIB"):  # A/B runs against an alternative build of the library
+    L.LIB_PATH = os.path.abspath(os.environ["DVAE_EXP_LIB"])
 
 
 def main():
