@@ -205,7 +205,7 @@ def main():
     opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
 
     # pre-packed batches: weak scaling, every rank owns B graphs per step
-    B = cfg["B"]
+    B = int(os.environ.get("DVAE_BENCH_B", cfg["B"]))  # diagnostic override (batch-size sweeps); not a bench line
     n_batches = cfg.get("n_batches", 4)
     t0 = time.perf_counter()
     batches = []

@@ -37,6 +37,14 @@ class DvaeHipError(RuntimeError):
     pass
 
 
+class LevelDesc(C.Structure):
+    """dvae_level_desc (include/dvae_hip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("a", "w", "gi_tab", "types", "bhn", "gates", "ghn", "hout", "gv_row", "gm",
+                                          "msg", "next_agg", "next_off", "idx", "dx", "hprev", "dgh", "dgin", "dhprev")] + \
+               [(n, C.c_int32) for n in ("lda", "K", "ld_hout", "ld_msg", "cur_row0", "ld_agg", "ld_dx", "ld_hprev",
+                                         "ld_dhprev")]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _F = C.c_float
@@ -60,6 +68,7 @@ SIGNATURES = {
     "dvae_gru_level_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dvae_gru_level_bwd": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dvae_level_dgrad_acc": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "dvae_chain_level_batch": (_I, [_I, C.POINTER(LevelDesc), _I, _I, _I, _P]),
     "dvae_gated_level_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_segment_colsum_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "dvae_pair_mask_words": (C.c_int64, [_I, _I]),

@@ -28,12 +28,16 @@
 
 namespace dvae {
 
+// Two shapes of workgroup, template parameter KS = number of K slices of a step:
+//   KS = 4: 512 threads, 64-deep K steps, 87 KB LDS (GRU) -- two waves per SIMD inside ONE workgroup; the
+//           choice when the grid is a single round of the chip (the decoder's chain: 256 workgroups)
+//   KS = 2: 256 threads, 32-deep K steps, 46 KB LDS -- two or three workgroups share a CU, so one's
+//           cold prologue and epilogue hide under another's K loop; the choice when the grid has at
+//           least two workgroups per CU (both encoder directions in one grid, large batches)
+// Either way a wave contracts 16 k (two groups of 8) of each step for its 32 rows and all gates.
 constexpr int CBM = 64;        // rows per workgroup
 constexpr int CBH = 32;        // hidden units (output columns per gate) per workgroup
-constexpr int CBK = 64;        // K step: four quarters of 16, one per wave pair
-constexpr int CLD = CBK + 4;   // LDS row stride of a K-contiguous image (floats)
-constexpr int CLW = 40;        // LDS row stride of the K-major W image [64 k][32 cols]: lane halves 4 k rows apart hit disjoint banks
-constexpr int CNT = 512;       // threads per workgroup
+constexpr int CLW = 40;        // LDS row stride of the K-major W image [BK k][32 cols]: lane halves 4 k rows apart hit disjoint banks
 
 struct ChainParams {
     const float* A; int lda;   // [M][K] K-contiguous operand (states, or dY of the backward products)
@@ -79,6 +83,9 @@ __device__ __forceinline__ void prefetch_unrolled(F& gload) {
 #endif
 
 // ---------------------------------------------------------------------------------- tails
+// (Loading a tail's operands -- table rows, biases, h_prev, stored gates, dX -- before the K loop
+// was measured: no change per kernel, and the extra live registers (GRU forward 146 -> 202) keep the
+// side stream's kernels off the CUs the chain occupies: loss forward 0.86 -> 0.97 ms.  Not done.)
 // GRUCell tail for 4 consecutive hidden units of one row (same arithmetic as gru_fwd_kernel)
 __device__ __forceinline__ void gru_tail(const ChainParams& p, int row, int col, float4 ghr, float4 ghz, float4 ghn) {
     const float* gi = p.gi_tab + (long)p.types[row] * 3 * p.Hp;
@@ -161,52 +168,58 @@ __device__ __forceinline__ void gru_bwd_tail(const ChainParams& p, int row, int 
 
 // ---------------------------------------------------------------------------------- epilogue
 // TAIL: 0 GRU forward (NGATE 3), 1 gate/mapper forward (NGATE 2), 2 dX += (NGATE 1), 3 dX += then GRU backward.
-// The wave of K quarter KQ finishes register quad KQ (columns 8 KQ + 4 (lane / 32) .. + 3): it
-// hands the other three quads to their owners through LDS, adds the three partial sums it
-// receives and its own IN K ORDER, and runs the tail.
-template <int NGATE, int TAIL, int KQ>
+// The wave of K slice KQ finishes 4 / KS register quads (quad q = columns 8 q + 4 (lane / 32) .. + 3):
+// it hands the other quads to their owners through LDS, adds the partial sums it receives and
+// its own IN K ORDER, and runs the tail.
+template <int NGATE, int TAIL, int KS, int KQ>
 __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&acc)[NGATE], float* lds, int m0, int n0,
                                                int wm, int lane) {
+    constexpr int QPW = 4 / KS;  // register quads a wave finishes: quads KQ * QPW .. + QPW - 1
     float4* xch = reinterpret_cast<float4*>(lds);
-    // slot of (destination quad q, source quarter k != q): ((q * 3 + (k < q ? k : k - 1)) * 2 + wm) * NGATE + gate
+    // slot of (destination quad q, source slice k != owner of q): ((q * (KS-1) + (k < owner ? k : k - 1)) * 2 + wm) * NGATE + gate
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (q == KQ) continue;
-        const int src = KQ < q ? KQ : KQ - 1;
+        const int owner = q / QPW;
+        if (owner == KQ) continue;
+        const int src = KQ < owner ? KQ : KQ - 1;
 #pragma unroll
         for (int i = 0; i < NGATE; ++i)
-            xch[(((q * 3 + src) * 2 + wm) * NGATE + i) * 64 + lane] =
+            xch[(((q * (KS - 1) + src) * 2 + wm) * NGATE + i) * 64 + lane] =
                 make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
     }
     __syncthreads();
     const int row = m0 + wm * 32 + (lane & 31), h = lane >> 5;
-    float4 v[NGATE];
-#pragma unroll
-    for (int i = 0; i < NGATE; ++i) {
-        const float4 own = make_float4(acc[i][4 * KQ], acc[i][4 * KQ + 1], acc[i][4 * KQ + 2], acc[i][4 * KQ + 3]);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // K quarters 0, 1, 2, 3 in order
-            float4 t;
-            if (k == KQ) t = own;
-            else t = xch[(((KQ * 3 + (k < KQ ? k : k - 1)) * 2 + wm) * NGATE + i) * 64 + lane];
-            if (k == 0) s = t;
-            else { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-        }
-        v[i] = s;
-    }
     if (row >= p.M) return;
-    const int col = n0 + 8 * KQ + 4 * h;
-    if (TAIL == 0) {
-        gru_tail(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
-    } else if (TAIL == 1) {
-        gate_tail(p, row, col, v[0], v[NGATE - 1]);
-    } else {
-        float* c = p.C + (long)row * p.ldc + col;
-        const float4 c0 = cld4(c);
-        const float4 d = make_float4(c0.x + v[0].x, c0.y + v[0].y, c0.z + v[0].z, c0.w + v[0].w);
-        cst4(c, d);
-        if (TAIL == 3) gru_bwd_tail(p, row, col, d);
+#pragma unroll
+    for (int ql = 0; ql < QPW; ++ql) {
+        const int q = KQ * QPW + ql;
+        float4 v[NGATE];
+#pragma unroll
+        for (int i = 0; i < NGATE; ++i) {
+            const float4 own = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {  // K slices 0 .. KS-1 in order
+                float4 t;
+                if (k == KQ) t = own;
+                else t = xch[(((q * (KS - 1) + (k < KQ ? k : k - 1)) * 2 + wm) * NGATE + i) * 64 + lane];
+                if (k == 0) s = t;
+                else { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            }
+            v[i] = s;
+        }
+        const int col = n0 + 8 * q + 4 * h;
+        if (TAIL == 0) {
+            gru_tail(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
+        } else if (TAIL == 1) {
+            gate_tail(p, row, col, v[0], v[NGATE - 1]);
+        } else {
+            float* c = p.C + (long)row * p.ldc + col;
+            const float4 c0 = cld4(c);
+            const float4 d = make_float4(c0.x + v[0].x, c0.y + v[0].y, c0.z + v[0].z, c0.w + v[0].w);
+            cst4(c, d);
+            if (TAIL == 3) gru_bwd_tail(p, row, col, d);
+        }
     }
 }
 
@@ -219,14 +232,25 @@ __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&ac
 //
 // WKM = false: forward product, W [NGATE * Hp][K] K-contiguous (TAIL 0 / 1)
 // WKM = true:  backward product, W [K][Hp] (NGATE = 1, TAIL 2 / 3)
-template <int NGATE, bool WKM, int TAIL, int PF, int NK>
-__global__ __launch_bounds__(CNT) void chain_kernel(ChainParams p) {
+// up to two independent levels of the same shape in one launch (blockIdx.y): the two directions of
+// the bidirectional encoder.  As separate launches on two streams they cannot share a CU (LDS and
+// register budgets) and only serialize with gaps; as one grid the second direction's workgroups
+// start on each CU the moment the first direction's finish.
+struct ChainBatch { ChainParams d[2]; };
+
+template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK>
+__global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
+    const ChainParams p = batch.d[blockIdx.y];
+    constexpr int CBK = 16 * KS;   // K step: KS slices of 16, one per wave pair
+    constexpr int CLD = CBK + 4;   // LDS row stride of a K-contiguous image (floats): ds_read_b128 conflict-free for 36 and 68
+    constexpr int C4R = CBK / 4;   // 16-byte units per K-contiguous tile row
     constexpr int A_ELEMS = CBM * CLD;
     constexpr int W_ELEMS = WKM ? CBK * CLW : NGATE * 32 * CLD;
     constexpr int STAGE = A_ELEMS + W_ELEMS;
     constexpr int WU = WKM ? 1 : NGATE;  // weight staging units (16 bytes) per thread; the A operand has 2
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-    static_assert(2 * STAGE * 4 >= 4 * 3 * 2 * NGATE * 64 * 16, "the K-quarter exchange reuses the stage buffers");
+    static_assert(KS == 2 || KS == 4, "two or four K slices");
+    static_assert(2 * STAGE * 4 >= 4 * (KS - 1) * 2 * NGATE * 64 * 16, "the K-slice exchange reuses the stage buffers");
     static_assert(NK % PF == 0 && (NK > 0 || PF == 1), "PF must divide the step count");
     static_assert(!WKM || NGATE == 1, "backward products have one output block per wave");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,9 +258,9 @@ __global__ __launch_bounds__(CNT) void chain_kernel(ChainParams p) {
     int m0, n0;
     tile_origin<CBM, CBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
 
-    // A: thread -> rows tid/16 and tid/16 + 32, 16 bytes at k (tid%16)*4
-    // W K-contiguous: rows tid/16 of each gate block, the same k;  W K-major: k row tid/8, columns (tid%8)*4
-    const int ar = tid >> 4, ak = (tid & 15) * 4;
+    // A: thread -> rows tid/C4R and tid/C4R + 32, 16 bytes at k (tid%C4R)*4
+    // W K-contiguous: rows tid/C4R of each gate block, the same k;  W K-major: k row tid/8, columns (tid%8)*4
+    const int ar = tid / C4R, ak = (tid % C4R) * 4;
     const float *pa0, *pa1, *pw0, *pw1, *pw2;
     {
         int r = m0 + ar;
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(CNT) void chain_kernel(ChainParams p) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto lstore = [&](auto S, float* st, int tile) {
         constexpr int s_ = decltype(S)::value;
-        const bool past = tile * CBK + ak >= p.K;  // only in the last step of a K with K % 64 == 32
+        const bool past = tile * CBK + ak >= p.K;  // only in the last step of a K with K % 64 == 32 (KS = 4)
         cst4(st + sa, past ? zero4 : rs[s_][0]);
         cst4(st + sa + 32 * CLD, past ? zero4 : rs[s_][1]);
         cst4(st + sw, rs[s_][2]);
@@ -345,43 +369,105 @@ __global__ __launch_bounds__(CNT) void chain_kernel(ChainParams p) {
     } else {
         for (int t = 0; t < nk; ++t) step(IC<0>{}, t);
     }
-    // (wave-uniform switch: the quad a wave finishes must be a compile-time register index)
-    switch (kq) {
-    case 0: chain_epilogue<NGATE, TAIL, 0>(p, acc, lds, m0, n0, wm, lane); break;
-    case 1: chain_epilogue<NGATE, TAIL, 1>(p, acc, lds, m0, n0, wm, lane); break;
-    case 2: chain_epilogue<NGATE, TAIL, 2>(p, acc, lds, m0, n0, wm, lane); break;
-    default: chain_epilogue<NGATE, TAIL, 3>(p, acc, lds, m0, n0, wm, lane); break;
+    // (wave-uniform branches: the quads a wave finishes must be compile-time register indices)
+    if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0>(p, acc, lds, m0, n0, wm, lane);
+    else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1>(p, acc, lds, m0, n0, wm, lane);
+    else if constexpr (KS == 4) {
+        if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2>(p, acc, lds, m0, n0, wm, lane);
+        else chain_epilogue<NGATE, TAIL, KS, 3>(p, acc, lds, m0, n0, wm, lane);
     }
 }
 
 // ---------------------------------------------------------------------------------- host
-template <int NGATE, bool WKM, int TAIL>
-static int chain_launch(ChainParams& p, hipStream_t s) {
-    p.tiles_x = p.Hp / CBH;
-    p.tiles_y = cdiv(p.M, CBM);
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(CNT);
+template <int NGATE, bool WKM, int TAIL, int KS>
+static int chain_launch_ks(ChainBatch& b, int count, hipStream_t s) {
+    const ChainParams& p = b.d[0];
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)count), block(128 * KS);
+    constexpr int BK = 16 * KS;
 #define CHAIN_CASE(NK_) \
-    case NK_: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, CHAIN_PF, NK_>), grid, block, 0, s, p); break;
-    // K = Hp (forward) and 2Hp / 3Hp (backward) for Hp = 512 (hs 501) and 1024 get the unrolled K loop
-    switch (p.K % CBK == 0 ? p.K / CBK : 0) {
-        CHAIN_CASE(8)
-        CHAIN_CASE(16)
-        CHAIN_CASE(24)
-        CHAIN_CASE(32)
-        CHAIN_CASE(48)
-    default: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, 1, 0>), grid, block, 0, s, p); break;
+    case NK_: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, CHAIN_PF, NK_>), grid, block, 0, s, b); break;
+    // The unrolled K loop is built for the 8-wave shape at K = Hp, 2Hp, 3Hp of Hp = 512 (hs 501: 8, 16
+    // and 24 steps); deeper unrolls make hipcc hoist loads until the registers spill, and the
+    // 4-wave shape needs its registers for co-residency: those run the runtime loop.
+    int nk = 0;
+    if constexpr (KS == 4) nk = p.K % BK == 0 ? p.K / BK : 0;
+    if constexpr (KS == 4 && !WKM) {
+        switch (nk) {
+            CHAIN_CASE(8)
+        default: nk = 0; break;
+        }
+    } else if constexpr (KS == 4) {
+        switch (nk) {
+            CHAIN_CASE(8)
+            CHAIN_CASE(16)
+            CHAIN_CASE(24)
+        default: nk = 0; break;
+        }
     }
+    if (nk == 0) hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, 1, 0>), grid, block, 0, s, b);
 #undef CHAIN_CASE
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
 
-static int chain_check(const float* A, int lda, int K, const float* W, int rows, int Hp) {
-    DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
+template <int NGATE, bool WKM, int TAIL>
+static int chain_launch(ChainBatch& b, int count, hipStream_t s) {
+    for (int i = 0; i < count; ++i) {
+        b.d[i].tiles_x = b.d[i].Hp / CBH;
+        b.d[i].tiles_y = cdiv(b.d[i].M, CBM);
+    }
+    // DVAE_CHAIN_KS = 2 / 4 forces the workgroup shape (A/B runs)
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_KS"); return v ? atoi(v) : 0; }();
+    const long wgs = (long)b.d[0].tiles_x * b.d[0].tiles_y * count;
+    (void)wgs;
+    const int ks = knob == 2 || knob == 4 ? knob : 4;
+    return ks == 2 ? chain_launch_ks<NGATE, WKM, TAIL, 2>(b, count, s) : chain_launch_ks<NGATE, WKM, TAIL, 4>(b, count, s);
+}
+
+static inline bool al16(const void* q) { return ((uintptr_t)q % 16) == 0; }
+static inline bool ldok(int ld, int w) { return ld >= w && ld % 4 == 0; }
+
+// descriptor -> kernel parameters, with the checks of the operation
+static int chain_fill(int op, const dvae_level_desc& v, int rows, int Hp, ChainParams& p) {
+    p = ChainParams{};
+    const int K = (op == DVAE_LEVEL_GRU_FWD || op == DVAE_LEVEL_GATED_FWD) ? Hp : v.K;
     DVAE_REQUIRE(K >= 32 && K % 32 == 0, "chain level: K must be a positive multiple of 32 (K=%d)", K);
-    DVAE_REQUIRE(A && W, "chain level: null operand");
-    DVAE_REQUIRE(lda >= K && lda % 4 == 0, "chain level: bad leading dimension %d", lda);
-    DVAE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "chain level: operands must be 16-byte aligned");
+    DVAE_REQUIRE(v.a && v.w && al16(v.a) && al16(v.w), "chain level: operands must be non-null and 16-byte aligned");
+    DVAE_REQUIRE(ldok(v.lda, K), "chain level: bad leading dimension %d of the operand", v.lda);
+    p.A = v.a; p.lda = v.lda; p.W = v.w; p.ldw = Hp; p.M = rows; p.Hp = Hp; p.K = K;
+    switch (op) {
+    case DVAE_LEVEL_GRU_FWD:
+        DVAE_REQUIRE(v.gi_tab && v.types && v.bhn && v.gates && v.ghn && v.hout, "gru level fwd: null pointer");
+        DVAE_REQUIRE(ldok(v.ld_hout, Hp), "gru level fwd: bad ld_hout %d", v.ld_hout);
+        DVAE_REQUIRE(al16(v.gi_tab) && al16(v.bhn) && al16(v.gates) && al16(v.ghn) && al16(v.hout),
+                     "gru level fwd: buffers must be 16-byte aligned");
+        p.gi_tab = v.gi_tab; p.types = v.types; p.bhn = v.bhn; p.hprev = v.a; p.ld_hprev = v.lda;
+        p.gates = v.gates; p.ghn = v.ghn; p.hout = v.hout; p.ld_hout = v.ld_hout;
+        break;
+    case DVAE_LEVEL_GATED_FWD:
+        DVAE_REQUIRE(v.gv_row && v.gm && v.msg, "gated level fwd: null pointer");
+        DVAE_REQUIRE(!v.next_agg || (v.next_off && v.idx), "gated level fwd: next_agg needs the CSR lists");
+        DVAE_REQUIRE(ldok(v.ld_msg, Hp) && (!v.next_agg || ldok(v.ld_agg, Hp)), "gated level fwd: bad leading dimension");
+        DVAE_REQUIRE(al16(v.gv_row) && al16(v.gm) && al16(v.msg) && al16(v.next_agg),
+                     "gated level fwd: buffers must be 16-byte aligned");
+        p.gv = v.gv_row; p.gm = v.gm; p.msg = v.msg; p.ld_msg = v.ld_msg; p.cur_row0 = v.cur_row0;
+        p.next_agg = v.next_agg; p.ld_agg = v.ld_agg; p.next_off = v.next_off; p.idx = v.idx;
+        break;
+    case DVAE_LEVEL_GRU_BWD:
+        DVAE_REQUIRE(v.gates && v.ghn && v.hprev && v.dgh && v.dgin && v.dhprev, "gru level bwd: null pointer");
+        DVAE_REQUIRE(ldok(v.ld_hprev, Hp) && ldok(v.ld_dhprev, Hp), "gru level bwd: bad leading dimension");
+        DVAE_REQUIRE(al16(v.gates) && al16(v.ghn) && al16(v.hprev) && al16(v.dgh) && al16(v.dgin) && al16(v.dhprev),
+                     "gru level bwd: buffers must be 16-byte aligned");
+        p.gates = v.gates; p.ghn = v.ghn; p.hprev = v.hprev; p.ld_hprev = v.ld_hprev;
+        p.dgh = v.dgh; p.dgin = v.dgin; p.dhprev = v.dhprev; p.ld_dhprev = v.ld_dhprev;
+        // fall through: dx is checked below
+    case DVAE_LEVEL_DGRAD_ACC:
+        DVAE_REQUIRE(v.dx && ldok(v.ld_dx, Hp) && al16(v.dx), "level dgrad: bad dx / ld_dx");
+        p.C = v.dx; p.ldc = v.ld_dx;
+        break;
+    default:
+        return set_err(DVAE_ERR_ARG, "chain level: unknown operation %d", op);
+    }
     return DVAE_OK;
 }
 
@@ -389,69 +475,57 @@ static int chain_check(const float* A, int lda, int K, const float* W, int rows,
 
 using namespace dvae;
 
+extern "C" int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows,
+                                      int32_t Hp, void* stream) {
+    DVAE_REQUIRE(levels && count >= 1 && count <= 2, "chain level batch: 1 or 2 levels per launch (got %d)", count);
+    DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
+    if (rows == 0) return DVAE_OK;
+    ChainBatch b;
+    for (int i = 0; i < count; ++i) DVAE_TRY(chain_fill(op, levels[i], rows, Hp, b.d[i]));
+    if (count == 1) b.d[1] = b.d[0];
+    DVAE_REQUIRE(b.d[1].K == b.d[0].K, "chain level batch: the levels of a launch share K");
+    hipStream_t s = (hipStream_t)stream;
+    switch (op) {
+    case DVAE_LEVEL_GRU_FWD: return chain_launch<3, false, 0>(b, count, s);
+    case DVAE_LEVEL_GATED_FWD: return chain_launch<2, false, 1>(b, count, s);
+    case DVAE_LEVEL_DGRAD_ACC: return chain_launch<1, true, 2>(b, count, s);
+    default: return chain_launch<1, true, 3>(b, count, s);
+    }
+}
+
 extern "C" int dvae_gru_level_fwd(const float* hprev, int32_t ld_hprev, const float* whh, const float* gi_tab,
                                   const int32_t* types, const float* bhn, float* gates, float* ghn_out, float* hout,
                                   int32_t ld_hout, int32_t rows, int32_t Hp, void* stream) {
-    if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(hprev, ld_hprev, Hp, whh, rows, Hp));
-    DVAE_REQUIRE(gi_tab && types && bhn && gates && ghn_out && hout, "gru_level_fwd: null pointer");
-    DVAE_REQUIRE(ld_hout >= Hp && ld_hout % 4 == 0, "gru_level_fwd: bad ld_hout %d", ld_hout);
-    DVAE_REQUIRE(((uintptr_t)gi_tab % 16) == 0 && ((uintptr_t)bhn % 16) == 0 && ((uintptr_t)gates % 16) == 0 &&
-                     ((uintptr_t)ghn_out % 16) == 0 && ((uintptr_t)hout % 16) == 0,
-                 "gru_level_fwd: buffers must be 16-byte aligned");
-    ChainParams p = {};
-    p.A = hprev; p.lda = ld_hprev; p.W = whh; p.ldw = Hp; p.M = rows; p.Hp = Hp; p.K = Hp;
-    p.gi_tab = gi_tab; p.types = types; p.bhn = bhn; p.hprev = hprev; p.ld_hprev = ld_hprev;
-    p.gates = gates; p.ghn = ghn_out; p.hout = hout; p.ld_hout = ld_hout;
-    return chain_launch<3, false, 0>(p, (hipStream_t)stream);
+    dvae_level_desc v = {};
+    v.a = hprev; v.lda = ld_hprev; v.w = whh; v.gi_tab = gi_tab; v.types = types; v.bhn = bhn;
+    v.gates = gates; v.ghn = ghn_out; v.hout = hout; v.ld_hout = ld_hout;
+    return dvae_chain_level_batch(DVAE_LEVEL_GRU_FWD, &v, 1, rows, Hp, stream);
 }
 
 extern "C" int dvae_gated_level_fwd(const float* h, int32_t ld_h, const float* wgm, const float* gv_row, float* gm,
                                     float* msg, int32_t ld_msg, int32_t cur_row0, float* next_agg, int32_t ld_agg,
                                     const int32_t* next_off, const int32_t* idx, int32_t rows, int32_t Hp,
                                     void* stream) {
-    if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(h, ld_h, Hp, wgm, rows, Hp));
-    DVAE_REQUIRE(gv_row && gm && msg, "gated_level_fwd: null pointer");
-    DVAE_REQUIRE(!next_agg || (next_off && idx), "gated_level_fwd: next_agg needs the CSR lists");
-    DVAE_REQUIRE(ld_msg >= Hp && ld_msg % 4 == 0 && (!next_agg || (ld_agg >= Hp && ld_agg % 4 == 0)),
-                 "gated_level_fwd: bad leading dimension");
-    DVAE_REQUIRE(((uintptr_t)gv_row % 16) == 0 && ((uintptr_t)gm % 16) == 0 && ((uintptr_t)msg % 16) == 0 &&
-                     ((uintptr_t)next_agg % 16) == 0,
-                 "gated_level_fwd: buffers must be 16-byte aligned");
-    ChainParams p = {};
-    p.A = h; p.lda = ld_h; p.W = wgm; p.ldw = Hp; p.M = rows; p.Hp = Hp; p.K = Hp;
-    p.gv = gv_row; p.gm = gm; p.msg = msg; p.ld_msg = ld_msg; p.cur_row0 = cur_row0;
-    p.next_agg = next_agg; p.ld_agg = ld_agg; p.next_off = next_off; p.idx = idx;
-    return chain_launch<2, false, 1>(p, (hipStream_t)stream);
+    dvae_level_desc v = {};
+    v.a = h; v.lda = ld_h; v.w = wgm; v.gv_row = gv_row; v.gm = gm; v.msg = msg; v.ld_msg = ld_msg;
+    v.cur_row0 = cur_row0; v.next_agg = next_agg; v.ld_agg = ld_agg; v.next_off = next_off; v.idx = idx;
+    return dvae_chain_level_batch(DVAE_LEVEL_GATED_FWD, &v, 1, rows, Hp, stream);
 }
 
 extern "C" int dvae_level_dgrad_acc(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dx, int32_t ld_dx,
                                     int32_t rows, int32_t Hp, void* stream) {
-    if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(dy, ld_dy, K, w, rows, Hp));
-    DVAE_REQUIRE(dx && ld_dx >= Hp && ld_dx % 4 == 0 && ((uintptr_t)dx % 16) == 0, "level_dgrad_acc: bad dx / ld_dx");
-    ChainParams p = {};
-    p.A = dy; p.lda = ld_dy; p.W = w; p.ldw = Hp; p.C = dx; p.ldc = ld_dx; p.M = rows; p.Hp = Hp; p.K = K;
-    return chain_launch<1, true, 2>(p, (hipStream_t)stream);
+    dvae_level_desc v = {};
+    v.a = dy; v.lda = ld_dy; v.K = K; v.w = w; v.dx = dx; v.ld_dx = ld_dx;
+    return dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &v, 1, rows, Hp, stream);
 }
 
 extern "C" int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w, float* dh, int32_t ld_dh,
                                   const float* gates, const float* ghn, const float* hprev, int32_t ld_hprev,
                                   float* dgh, float* dgin, float* dhprev, int32_t ld_dhprev, int32_t rows, int32_t Hp,
                                   void* stream) {
-    if (rows == 0) return DVAE_OK;
-    DVAE_TRY(chain_check(dy, ld_dy, K, w, rows, Hp));
-    DVAE_REQUIRE(dh && ld_dh >= Hp && ld_dh % 4 == 0 && ((uintptr_t)dh % 16) == 0, "gru_level_bwd: bad dh / ld_dh");
-    DVAE_REQUIRE(gates && ghn && hprev && dgh && dgin && dhprev, "gru_level_bwd: null pointer");
-    DVAE_REQUIRE(ld_hprev >= Hp && ld_hprev % 4 == 0 && ld_dhprev >= Hp && ld_dhprev % 4 == 0,
-                 "gru_level_bwd: bad leading dimension");
-    DVAE_REQUIRE(((uintptr_t)gates % 16) == 0 && ((uintptr_t)ghn % 16) == 0 && ((uintptr_t)hprev % 16) == 0 &&
-                     ((uintptr_t)dgh % 16) == 0 && ((uintptr_t)dgin % 16) == 0 && ((uintptr_t)dhprev % 16) == 0,
-                 "gru_level_bwd: buffers must be 16-byte aligned");
-    ChainParams p = {};
-    p.A = dy; p.lda = ld_dy; p.W = w; p.ldw = Hp; p.C = dh; p.ldc = ld_dh; p.M = rows; p.Hp = Hp; p.K = K;
-    p.gates = const_cast<float*>(gates); p.ghn = const_cast<float*>(ghn); p.hprev = hprev; p.ld_hprev = ld_hprev;
-    p.dgh = dgh; p.dgin = dgin; p.dhprev = dhprev; p.ld_dhprev = ld_dhprev;
-    return chain_launch<1, true, 3>(p, (hipStream_t)stream);
+    dvae_level_desc v = {};
+    v.a = dy; v.lda = ld_dy; v.K = K; v.w = w; v.dx = dh; v.ld_dx = ld_dh;
+    v.gates = const_cast<float*>(gates); v.ghn = const_cast<float*>(ghn); v.hprev = hprev; v.ld_hprev = ld_hprev;
+    v.dgh = dgh; v.dgin = dgin; v.dhprev = dhprev; v.ld_dhprev = ld_dhprev;
+    return dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, &v, 1, rows, Hp, stream);
 }

@@ -270,15 +270,32 @@ extern "C" int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batc
 }
 
 // The chain levels of the fp32 mode run the fused level kernels of chain.hip (hidden product +
-// pointwise tail in one launch); DVAE_CHAIN_FUSED=0 falls back to GEMM + pointwise launches (A/B runs).
-static bool chain_fused(const Dims& d) {
+// pointwise tail in one launch); DVAE_CHAIN_FUSED=0 falls back to GEMM + pointwise launches (A/B runs),
+// =2 forces them for every level size.
+// They pay for levels of one to two rounds of the chip (64 x 32 tiles; cfg 2 / cfg 4: 256 workgroups,
+// +5 % / +4 % on the step).  Smaller levels leave CUs idle where the generic kernel's split-K and
+// small tiles spread the work (same-box sweep of cfg 2 at B = 64 / 128 / 256 / 512: -7 / -8 / -5 / 0 %),
+// and a larger level (cfg 5: 2048 rows x Hp 1024 = 4 rounds) is a well-shaped product for the
+// 128 x 128 tiles of gemm.hip, whose operand reuse then wins (6.08 k vs 5.93 k DAGs/s).
+static bool chain_level_small(const Dims& d, int B) {
+    const long tiles = (long)cdiv(B, 64) * (d.Hp / 32);
+    return tiles >= 256 && tiles <= 512;
+}
+static bool chain_fused(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
-    return knob != 0 && !d.bf16 && !d.bn;
+    return (knob == 2 || (knob == 1 && chain_level_small(d, B))) && !d.bf16 && !d.bn;
+}
+// both encoder directions of a level as one grid (dvae_chain_level_batch) instead of two streams:
+// measured no faster forward (0.64 ms either way) and slower backward (1.08 -> 1.27 ms), because
+// workgroups launched together run in lockstep and nothing overlaps; kept behind DVAE_CHAIN_MERGE=1
+static bool chain_merge_dirs() {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_MERGE"); return v ? atoi(v) : 0; }();
+    return knob != 0;
 }
 // the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD=0 falls back
-static bool chain_fused_bwd(const Dims& d) {
+static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
-    return knob != 0 && !d.bf16 && !d.bn;
+    return (knob == 2 || (knob == 1 && chain_level_small(d, B))) && !d.bf16 && !d.bn;
 }
 
 // =====================================================================================
@@ -297,7 +314,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
     const int dirs = d.bidir ? 2 : 1;
-    const bool fused = chain_fused(d);
+    const bool fused = chain_fused(d, c->B);
 
     // DVAE_BN has no recurrence: each direction is one batched pass over all levels.
     auto run_dir_bn = [&](int k, hipStream_t s) -> int {
@@ -347,21 +364,49 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     // The two directions are independent chains of small dependent launches; they run on two
     // streams and are ENQUEUED level by level in turn, so that neither stream starves while the
     // host is still issuing the other one's launches.
+    // (optional, DVAE_CHAIN_MERGE=1: both directions of a level as ONE grid on the caller's stream,
+    // dvae_chain_level_batch, instead of two streams)
+    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
     Side* side = nullptr;
-    if (dirs == 2) {
+    if (dirs == 2 && !merged) {
         DVAE_TRY(side_for_current_device(&side));
         DVAE_TRY(fork_side(side, s));
     }
     if (d.bn) {
         if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
         DVAE_TRY(run_dir_bn(0, s));
+    } else if (merged) {
+        // first level of each direction: no predecessors, h_prev = 0 (the product over zeros is exact)
+        DVAE_HIP(hipMemsetAsync(w.agg[0], 0, sizeof(float) * (size_t)B * Hp, s));
+        DVAE_HIP(hipMemsetAsync(w.agg[1] + (size_t)(n - 1) * B * Hp, 0, sizeof(float) * (size_t)B * Hp, s));
+        for (int step = 0; step < n; ++step) {
+            dvae_level_desc gru[2] = {}, gat[2] = {};
+            for (int k = 0; k < 2; ++k) {
+                const int v = k == 0 ? step : n - 1 - step;
+                const long r0 = (long)v * B, r1 = (long)(k == 0 ? v + 1 : v - 1) * B;
+                gru[k].a = w.agg[k] + r0 * Hp; gru[k].lda = Hp; gru[k].w = pw + L.whh[k];
+                gru[k].gi_tab = pw + L.gi[k]; gru[k].types = bv.types + r0; gru[k].bhn = pw + L.bhn[k];
+                gru[k].gates = w.gates[k] + r0 * 3 * Hp; gru[k].ghn = w.ghn[k] + r0 * Hp;
+                gru[k].hout = w.hs[k] + r0 * Hp; gru[k].ld_hout = Hp;
+                if (step < n - 1) {
+                    gat[k].a = w.hs[k] + r0 * Hp; gat[k].lda = Hp; gat[k].w = pw + L.wgm[k];
+                    gat[k].gv_row = pw + L.gv[k] + (size_t)v * 2 * Hp; gat[k].gm = w.gm[k] + r0 * 2 * Hp;
+                    gat[k].msg = w.msg[k]; gat[k].ld_msg = Hp; gat[k].cur_row0 = (int)r0;
+                    gat[k].next_agg = w.agg[k] + r1 * Hp; gat[k].ld_agg = Hp;
+                    gat[k].next_off = (k == 0 ? bv.pred_off : bv.succ_off) + r1;
+                    gat[k].idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+                }
+            }
+            DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_FWD, gru, 2, B, Hp, s));
+            if (step < n - 1) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GATED_FWD, gat, 2, B, Hp, s));
+        }
     } else {
         for (int step = 0; step < n; ++step) {
             if (dirs == 2) DVAE_TRY(level(1, step, side->stream));
             DVAE_TRY(level(0, step, s));
         }
     }
-    if (dirs == 2) DVAE_TRY(join_side(side, s));
+    if (dirs == 2 && !merged) DVAE_TRY(join_side(side, s));
     // graph state (models.py:704-718 / 1006-1027)
     DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
     const float* hgu = w.hg;
@@ -391,7 +436,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, NZ2 = 2 * d.NZp;
     const int dirs = d.bidir ? 2 : 1;
-    const bool fused = chain_fused_bwd(d);
+    const bool fused = chain_fused_bwd(d, c->B);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
     EW(join_mu_logvar_kernel, (long)B * NZ2, w.d12, dmu, dlogvar, B, d.nz, d.NZp);
@@ -468,9 +513,11 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         return DVAE_OK;
     };
     // as in the forward pass: two streams, enqueued level by level in turn
+    // (as in the forward pass: optionally both directions of a level as one grid)
+    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
     Side* side = nullptr;
-    if (dirs == 2) {
-        DVAE_TRY(side_for_current_device(&side));
+    if (dirs == 2) DVAE_TRY(side_for_current_device(&side));
+    if (dirs == 2 && !merged) {
         DVAE_TRY(fork_side(side, s));
         DVAE_TRY(begin_dir(1, side->stream));
     }
@@ -478,6 +525,35 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     if (d.bn) {
         if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
         DVAE_TRY(run_dir_bn(0, s));
+    } else if (merged) {
+        DVAE_TRY(begin_dir(1, s));
+        for (int step = n - 1; step >= 0; --step) {
+            dvae_level_desc gb[2] = {}, da[2] = {};
+            for (int k = 0; k < 2; ++k) {
+                const int v = k == 0 ? step : n - 1 - step;
+                const long r0 = (long)v * B;
+                if (step < n - 1) {
+                    DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, (k == 0 ? bv.succ_off : bv.pred_off) + r0,
+                                                   k == 0 ? bv.succ_idx : bv.pred_idx, nullptr, nullptr, nullptr,
+                                                   w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
+                    gb[k].a = w.dgm[k] + r0 * 2 * Hp; gb[k].lda = 2 * Hp; gb[k].K = 2 * Hp; gb[k].w = pw + L.wgm[k];
+                    gb[k].dx = w.dhs[k] + r0 * Hp; gb[k].ld_dx = Hp;
+                    gb[k].gates = w.gates[k] + r0 * 3 * Hp; gb[k].ghn = w.ghn[k] + r0 * Hp;
+                    gb[k].hprev = w.agg[k] + r0 * Hp; gb[k].ld_hprev = Hp;
+                    gb[k].dgh = w.dgh[k] + r0 * 3 * Hp; gb[k].dgin = w.dgin[k] + r0 * Hp;
+                    gb[k].dhprev = w.dagg[k] + r0 * Hp; gb[k].ld_dhprev = Hp;
+                } else {  // last vertex of the pass: no message left it
+                    DVAE_TRY(dvae_gru_pointwise_bwd(w.dhs[k] + r0 * Hp, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp,
+                                                    w.agg[k] + r0 * Hp, Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp,
+                                                    w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
+                }
+                da[k].a = w.dgh[k] + r0 * 3 * Hp; da[k].lda = 3 * Hp; da[k].K = 3 * Hp; da[k].w = pw + L.whh[k];
+                da[k].dx = w.dagg[k] + r0 * Hp; da[k].ld_dx = Hp;
+            }
+            if (step < n - 1) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
+            if (step > 0) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, da, 2, B, Hp, s));
+        }
+        DVAE_TRY(fork_side(side, s));
     } else {
         for (int step = n - 1; step >= 0; --step) {
             if (dirs == 2) DVAE_TRY(level(1, step, side->stream));
@@ -520,7 +596,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
-    const bool fused = chain_fused(d);
+    const bool fused = chain_fused(d, c->B);
     if (fused) {
         DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
     } else {
@@ -619,7 +695,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp, NST = nB + PT;
     const float* whh = pw + L.whh[2];
-    const bool fused = chain_fused_bwd(d);
+    const bool fused = chain_fused_bwd(d, c->B);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
     hipLaunchKernelGGL(grad_scales_kernel, dim3(1), dim3(1), 0, s, g3, beta, w.gs);

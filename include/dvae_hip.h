@@ -143,6 +143,40 @@ int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w
                        const float* gates, const float* ghn, const float* hprev, int32_t ld_hprev, float* dgh,
                        float* dgin, float* dhprev, int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream);
 
+/* The four level operations above as ONE launch over up to two independent levels of the same
+ * shape (the two directions of the bidirectional encoder, models.py:724-727: as one grid the
+ * second direction's workgroups start on a CU the moment the first's finish, where two launches
+ * on two streams only serialize).  Fields a level operation does not use are ignored:
+ *   GRU_FWD    a = hprev (lda), w = whh, gi_tab, types, bhn -> gates, ghn, hout (ld_hout)
+ *   GATED_FWD  a = h (lda), w = wgm, gv_row -> gm, msg (ld_msg, cur_row0), next_agg (ld_agg, next_off, idx)
+ *   DGRAD_ACC  a = dy (lda), K, w -> dx (ld_dx)
+ *   GRU_BWD    a = dy (lda), K, w, gates, ghn, hprev (ld_hprev) -> dx = dh (ld_dx), dgh, dgin, dhprev (ld_dhprev) */
+enum { DVAE_LEVEL_GRU_FWD = 0, DVAE_LEVEL_GATED_FWD = 1, DVAE_LEVEL_DGRAD_ACC = 2, DVAE_LEVEL_GRU_BWD = 3 };
+typedef struct dvae_level_desc {
+    const float* a;
+    const float* w;
+    const float* gi_tab;
+    const int32_t* types;
+    const float* bhn;
+    float* gates;
+    float* ghn;
+    float* hout;
+    const float* gv_row;
+    float* gm;
+    float* msg;
+    float* next_agg;
+    const int32_t* next_off;
+    const int32_t* idx;
+    float* dx;
+    const float* hprev;
+    float* dgh;
+    float* dgin;
+    float* dhprev;
+    int32_t lda, K, ld_hout, ld_msg, cur_row0, ld_agg, ld_dx, ld_hprev, ld_dhprev;
+} dvae_level_desc;
+int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows, int32_t Hp,
+                           void* stream);
+
 /* out[seg][0:width] += sum over the seg_rows rows of segment seg of x */
 int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                             int32_t seg_rows, int32_t width, void* stream);

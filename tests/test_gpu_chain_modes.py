@@ -1,0 +1,27 @@
+"""The fused level kernels of csrc/chain.hip are chosen by level size (one to two rounds of the chip:
+BASELINE cfg 2 / cfg 4), so the small parity cases of test_gpu_parity.py run the GEMM + pointwise
+launches instead.  Here the same parity cases (reference golden vectors, oracle on random / ragged /
+64-vertex batches) are re-run in a child process with the fused kernels FORCED for every level size,
+in each of their modes: 8-wave workgroups, 4-wave workgroups, both encoder directions in one grid.
+(The knobs are read once per process, hence the child process; one at a time, GPU use stays at 2 processes.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FORCED = {"DVAE_CHAIN_FUSED": "2", "DVAE_CHAIN_FUSED_BWD": "2"}
+CASES = "tiny_matches_reference_golden or random_graphs_match_oracle or max_size_graphs_n64 or edge_cases_smallest"
+
+
+@pytest.mark.parametrize("extra", [{}, {"DVAE_CHAIN_KS": "2"}, {"DVAE_CHAIN_MERGE": "1"}],
+                         ids=["8-wave", "4-wave", "merged-directions"])
+def test_parity_with_fused_level_kernels_forced(extra):
+    env = dict(os.environ, **FORCED, **extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", CASES, "-p", "no:cacheprovider", "--timeout", "120", "--timeout-method", "thread"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

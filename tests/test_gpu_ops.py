@@ -602,3 +602,41 @@ def test_gru_level_bwd_fused_matches_dgrad_plus_pointwise(rows, Hp):
     assert (dh - dh_ref).abs().max() < 2e-5
     for a, b in zip(outs, outs_ref):
         assert torch.isfinite(a).all() and (a - b).abs().max() < 5e-5
+
+
+def test_chain_level_batch_two_levels_equals_two_launches():
+    """dvae_chain_level_batch with count = 2 (both encoder directions of a level in one grid) gives,
+    bit for bit, what two single-level launches give (same kernel, same summation order)."""
+    g = torch.Generator().manual_seed(77)
+    rows, Hp, T = 200, 64, 8
+    lib = L.load()
+
+    def mk():
+        return dict(hprev=torch.randn(rows, Hp, generator=g).cuda(),
+                    whh=(torch.randn(3 * Hp, Hp, generator=g) / Hp ** 0.5).cuda(),
+                    gi=torch.randn(T, 3 * Hp, generator=g).cuda(), bhn=torch.randn(Hp, generator=g).cuda(),
+                    types=torch.randint(0, T, (rows,), generator=g).int().cuda())
+
+    def outs():
+        return [torch.full((rows, 3 * Hp), float("nan")).cuda(), torch.full((rows, Hp), float("nan")).cuda(),
+                torch.full((rows, Hp), float("nan")).cuda()]
+
+    ins = [mk(), mk()]
+    single = [outs(), outs()]
+    for i, o in zip(ins, single):
+        L.check(lib.dvae_gru_level_fwd(i["hprev"].data_ptr(), Hp, i["whh"].data_ptr(), i["gi"].data_ptr(),
+                                       i["types"].data_ptr(), i["bhn"].data_ptr(), o[0].data_ptr(), o[1].data_ptr(),
+                                       o[2].data_ptr(), Hp, rows, Hp, _s()))
+    both = [outs(), outs()]
+    descs = (L.LevelDesc * 2)()
+    for k, (i, o) in enumerate(zip(ins, both)):
+        descs[k].a, descs[k].lda, descs[k].w = i["hprev"].data_ptr(), Hp, i["whh"].data_ptr()
+        descs[k].gi_tab, descs[k].types, descs[k].bhn = i["gi"].data_ptr(), i["types"].data_ptr(), i["bhn"].data_ptr()
+        descs[k].gates, descs[k].ghn, descs[k].hout, descs[k].ld_hout = o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), Hp
+    L.check(lib.dvae_chain_level_batch(0, descs, 2, rows, Hp, _s()))
+    torch.cuda.synchronize()
+    for a, b in zip(single, both):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # more than two levels per launch is refused
+    assert lib.dvae_chain_level_batch(0, descs, 3, rows, Hp, _s()) != 0
