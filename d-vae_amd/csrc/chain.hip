@@ -59,25 +59,8 @@ __device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cas
 __device__ __forceinline__ void cst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 template <int V>
 struct IC { static constexpr int value = V; };  // compile-time register-set index for the staging lambdas
-// steps t .. t+PF-1 of a K loop whose step count is a multiple of PF: the register set of tile
-// t+j+1 is the constant (j+1) % PF (t % PF == 0), and there is NO branch between the steps -- with
-// conditional loads hipcc's wait-count insertion falls back to s_waitcnt vmcnt(0) before every
-// LDS store, which drains all the tiles in flight.
-template <int J, int PF, class F>
-__device__ __forceinline__ void steps_unrolled(F& step, int t) {
-    if constexpr (J < PF) {
-        step(IC<(J + 1) % PF>{}, t + J);
-        steps_unrolled<J + 1, PF>(step, t);
-    }
-}
-// prologue: tiles 1 .. PF-1 -> sets 1 .. PF-1
-template <int J, int PF, class F>
-__device__ __forceinline__ void prefetch_unrolled(F& gload) {
-    if constexpr (J < PF) {
-        gload(IC<J>{}, J);
-        prefetch_unrolled<J + 1, PF>(gload);
-    }
-}
+// (The K loop has NO branch between its steps: with conditional loads hipcc's wait-count insertion
+// falls back to s_waitcnt vmcnt(0) before every LDS store, which drains all the tiles in flight.)
 #ifndef CHAIN_PF
 #define CHAIN_PF 2  // register-staged tiles in flight in the unrolled kernels (1, 2, 4 or 8; measured: no effect beyond 1)
 #endif
@@ -232,15 +215,35 @@ __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&ac
 //
 // WKM = false: forward product, W [NGATE * Hp][K] K-contiguous (TAIL 0 / 1)
 // WKM = true:  backward product, W [K][Hp] (NGATE = 1, TAIL 2 / 3)
-// up to two independent levels of the same shape in one launch (blockIdx.y): the two directions of
-// the bidirectional encoder.  As separate launches on two streams they cannot share a CU (LDS and
-// register budgets) and only serialize with gaps; as one grid the second direction's workgroups
-// start on each CU the moment the first direction's finish.
+// ND = 2: TWO independent levels of the same shape per workgroup (the two directions of the
+// bidirectional encoder): the K loop alternates between them step by step, each with its own
+// accumulators, so the per-workgroup latencies (cold first tile, epilogue) are paid once for both
+// while the MFMA work per workgroup doubles.  (As two grids -- blockIdx.y, or two streams -- the
+// directions only serialize: the level kernels of the two cannot share a CU, and workgroups
+// launched together run in lockstep.)
 struct ChainBatch { ChainParams d[2]; };
 
-template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK>
+// The loop runs over steps s = 0 .. nk * ND - 1: level s % ND, tile s / ND, LDS stage s & 1; the data of
+// step s + 1 sit in register set (s + 1) % PF.  Unrolled in groups of U = lcm(PF, ND) steps so that
+// sets and levels are compile-time constants (J = s % U).
+template <int J, int U, class F>
+__device__ __forceinline__ void chain_steps(F& step, int s) {
+    if constexpr (J < U) {
+        step(IC<J>{}, s + J);
+        chain_steps<J + 1, U>(step, s);
+    }
+}
+template <int J, int PF, class F>
+__device__ __forceinline__ void chain_prefetch(F& gload) {
+    if constexpr (J < PF) {
+        gload(IC<J>{}, J);
+        chain_prefetch<J + 1, PF>(gload);
+    }
+}
+
+template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK, int ND>
 __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
-    const ChainParams p = batch.d[blockIdx.y];
+    const ChainParams& p = batch.d[0];  // shape (M, Hp, K, tiles) is common to the levels of a launch
     constexpr int CBK = 16 * KS;   // K step: KS slices of 16, one per wave pair
     constexpr int CLD = CBK + 4;   // LDS row stride of a K-contiguous image (floats): ds_read_b128 conflict-free for 36 and 68
     constexpr int C4R = CBK / 4;   // 16-byte units per K-contiguous tile row
@@ -248,10 +251,12 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
     constexpr int W_ELEMS = WKM ? CBK * CLW : NGATE * 32 * CLD;
     constexpr int STAGE = A_ELEMS + W_ELEMS;
     constexpr int WU = WKM ? 1 : NGATE;  // weight staging units (16 bytes) per thread; the A operand has 2
+    constexpr int U = (PF % ND == 0) ? PF : PF * ND;  // lcm(PF, ND) for ND in {1, 2}
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
     static_assert(KS == 2 || KS == 4, "two or four K slices");
+    static_assert(ND == 1 || ND == 2, "one or two levels per workgroup");
     static_assert(2 * STAGE * 4 >= 4 * (KS - 1) * 2 * NGATE * 64 * 16, "the K-slice exchange reuses the stage buffers");
-    static_assert(NK % PF == 0 && (NK > 0 || PF == 1), "PF must divide the step count");
+    static_assert((NK * ND) % U == 0 && (NK > 0 || PF == 1), "the unroll group must divide the step count");
     static_assert(!WKM || NGATE == 1, "backward products have one output block per wave");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 1, wm = wave & 1;
@@ -261,48 +266,55 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
     // A: thread -> rows tid/C4R and tid/C4R + 32, 16 bytes at k (tid%C4R)*4
     // W K-contiguous: rows tid/C4R of each gate block, the same k;  W K-major: k row tid/8, columns (tid%8)*4
     const int ar = tid / C4R, ak = (tid % C4R) * 4;
-    const float *pa0, *pa1, *pw0, *pw1, *pw2;
-    {
+    const float *pa0[ND], *pa1[ND], *pw0[ND], *pw1[ND], *pw2[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const ChainParams& q = batch.d[d];
         int r = m0 + ar;
         r = r < p.M ? r : p.M - 1;  // clamped rows are computed but never stored
-        pa0 = p.A + (long)r * p.lda;
+        pa0[d] = q.A + (long)r * q.lda;
         r = m0 + ar + 32;
         r = r < p.M ? r : p.M - 1;
-        pa1 = p.A + (long)r * p.lda;
+        pa1[d] = q.A + (long)r * q.lda;
         if (!WKM) {
-            pw0 = p.W + (long)(n0 + ar) * p.ldw;
-            pw1 = pw0 + (long)p.Hp * p.ldw;
-            pw2 = pw1 + (long)p.Hp * p.ldw;
+            pw0[d] = q.W + (long)(n0 + ar) * q.ldw;
+            pw1[d] = pw0[d] + (long)p.Hp * q.ldw;
+            pw2[d] = pw1[d] + (long)p.Hp * q.ldw;
         } else {
-            pw0 = p.W + n0 + (tid & 7) * 4;
-            pw1 = pw2 = pw0;
+            pw0[d] = q.W + n0 + (tid & 7) * 4;
+            pw1[d] = pw2[d] = pw0[d];
         }
     }
     const int sa = ar * CLD + ak;
     const int sw = A_ELEMS + (WKM ? (tid >> 3) * CLW + (tid & 7) * 4 : ar * CLD + ak);
     const int nk = NK > 0 ? NK : (p.K + CBK - 1) / CBK;
+    const int ns_total = nk * ND;
+    // (Rotating each workgroup's K order by its column tile, so that workgroups walking K in step do not
+    // read the same k-slab at the same moment, was measured: no change -- L2 hit rate 82 %, see profiles/.)
+    auto tile_of = [&](int s) { const int t = s / ND; return t < nk ? t : nk - 1; };  // steps past the end reload the last tile
     float4 rs[PF][2 + WU];
-    auto gload = [&](auto S, int tile) {  // tiles past the end reload the last one (never used)
-        constexpr int s_ = decltype(S)::value;
-        const int k0 = (tile < nk ? tile : nk - 1) * CBK;
+    // loads the data of step s into register set (s % PF); s = J (mod U) gives set and level statically
+    auto gload = [&](auto Jc, int s) {
+        constexpr int s_ = decltype(Jc)::value % PF, d_ = decltype(Jc)::value % ND;
+        const int k0 = tile_of(s) * CBK;
         int ka = k0 + ak;
         ka = ka < p.K ? ka : ka - 32;
-        rs[s_][0] = cld4(pa0 + ka);
-        rs[s_][1] = cld4(pa1 + ka);
+        rs[s_][0] = cld4(pa0[d_] + ka);
+        rs[s_][1] = cld4(pa1[d_] + ka);
         if (!WKM) {
-            rs[s_][2] = cld4(pw0 + ka);
-            if (NGATE > 1) rs[s_][WU > 1 ? 3 : 2] = cld4(pw1 + ka);
-            if (NGATE > 2) rs[s_][WU > 2 ? 4 : 2] = cld4(pw2 + ka);
+            rs[s_][2] = cld4(pw0[d_] + ka);
+            if (NGATE > 1) rs[s_][WU > 1 ? 3 : 2] = cld4(pw1[d_] + ka);
+            if (NGATE > 2) rs[s_][WU > 2 ? 4 : 2] = cld4(pw2[d_] + ka);
         } else {
             int kw = k0 + (tid >> 3);
             kw = kw < p.K ? kw : kw - 32;
-            rs[s_][2] = cld4(pw0 + (long)kw * p.ldw);
+            rs[s_][2] = cld4(pw0[d_] + (long)kw * batch.d[d_].ldw);
         }
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto lstore = [&](auto S, float* st, int tile) {
-        constexpr int s_ = decltype(S)::value;
-        const bool past = tile * CBK + ak >= p.K;  // only in the last step of a K with K % 64 == 32 (KS = 4)
+    auto lstore = [&](auto Jc, float* st, int s) {  // register set (s % PF) -> LDS stage
+        constexpr int s_ = decltype(Jc)::value % PF;
+        const bool past = tile_of(s) * CBK + ak >= p.K;  // only in the last tile of a K with K % 64 == 32 (KS = 4)
         cst4(st + sa, past ? zero4 : rs[s_][0]);
         cst4(st + sa + 32 * CLD, past ? zero4 : rs[s_][1]);
         cst4(st + sw, rs[s_][2]);
@@ -310,27 +322,30 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
         if (!WKM && NGATE > 2) cst4(st + sw + 64 * CLD, rs[s_][WU > 2 ? 4 : 2]);
     };
 
-    f32x16 acc[NGATE];
+    f32x16 acc[ND][NGATE];
 #pragma unroll
-    for (int i = 0; i < NGATE; ++i)
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < NGATE; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][i][r] = 0.f;
 
-    // tiles 0 .. PF-1 -> sets 0 .. PF-1, tile 0 -> LDS, tile PF -> set 0
+    // steps 0 .. PF-1 -> sets 0 .. PF-1, step 0 -> LDS, step PF -> set 0
     gload(IC<0>{}, 0);
-    prefetch_unrolled<1, PF>(gload);
+    chain_prefetch<1, PF>(gload);
     lstore(IC<0>{}, lds, 0);
-    gload(IC<0>{}, PF);
+    gload(IC<PF>{}, PF);
     __syncthreads();
     // fragment bases of this wave: row (lane & 31) of its row half / of each gate image (or column
-    // lane & 31 of the K-major image), k offset of its K quarter (2 groups of 8 k) and lane half
+    // lane & 31 of the K-major image), k offset of its K slice (2 groups of 8 k) and lane half
     const int foa = (wm * 32 + (lane & 31)) * CLD + kq * 16 + 4 * (lane >> 5);
     const int fow = A_ELEMS + (WKM ? (kq * 16 + 4 * (lane >> 5)) * CLW + (lane & 31)
                                    : (lane & 31) * CLD + kq * 16 + 4 * (lane >> 5));
-    // step t computes tile t from stage t & 1; tile t+1 sits in register set (t+1) % PF
-    auto step = [&](auto S, int t) {
-        const float* cs = lds + (t & 1) * STAGE;
-        float* ns = lds + ((t & 1) ^ 1) * STAGE;
+    auto step = [&](auto Jc, int s) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int D = J % ND;  // level of the tile being contracted
+        const float* cs = lds + (s & 1) * STAGE;
+        float* ns = lds + ((s & 1) ^ 1) * STAGE;
         float4 fa[2], fw[2][NGATE];
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
@@ -348,44 +363,49 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].x, fa[gg].x, acc[i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].x, fa[gg].x, acc[D][i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].y, fa[gg].y, acc[i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].y, fa[gg].y, acc[D][i], 0, 0, 0);
             if (gg == 0) {
-                // tile t+1 (in flight for PF steps): registers -> the other stage; reload from tile t+1+PF
-                lstore(S, ns, t + 1);
-                gload(S, t + 1 + PF);
+                // step s+1 (in flight for PF steps): registers -> the other stage; reload from step s+1+PF
+                lstore(IC<J + 1>{}, ns, s + 1);
+                gload(IC<J + 1 + PF>{}, s + 1 + PF);
             }
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].z, fa[gg].z, acc[i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].z, fa[gg].z, acc[D][i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].w, fa[gg].w, acc[i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].w, fa[gg].w, acc[D][i], 0, 0, 0);
         }
-        __syncthreads();  // stage t^1 complete; every wave holds its fragments of stage t in registers
+        __syncthreads();  // stage s^1 complete; every wave holds its fragments of stage s in registers
     };
     if constexpr (NK > 0) {
 #pragma unroll
-        for (int t = 0; t < NK; t += PF) steps_unrolled<0, PF>(step, t);  // t % PF == 0: set indices are constants
+        for (int s = 0; s < NK * ND; s += U) chain_steps<0, U>(step, s);  // s % U == 0: sets and levels are constants
     } else {
-        for (int t = 0; t < nk; ++t) step(IC<0>{}, t);
+        for (int s = 0; s < ns_total; s += U) chain_steps<0, U>(step, s);
     }
     // (wave-uniform branches: the quads a wave finishes must be compile-time register indices)
-    if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0>(p, acc, lds, m0, n0, wm, lane);
-    else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1>(p, acc, lds, m0, n0, wm, lane);
-    else if constexpr (KS == 4) {
-        if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2>(p, acc, lds, m0, n0, wm, lane);
-        else chain_epilogue<NGATE, TAIL, KS, 3>(p, acc, lds, m0, n0, wm, lane);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (d > 0) __syncthreads();  // the exchange buffer is reused
+        const ChainParams& q = batch.d[d];
+        if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0>(q, acc[d], lds, m0, n0, wm, lane);
+        else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1>(q, acc[d], lds, m0, n0, wm, lane);
+        else if constexpr (KS == 4) {
+            if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2>(q, acc[d], lds, m0, n0, wm, lane);
+            else chain_epilogue<NGATE, TAIL, KS, 3>(q, acc[d], lds, m0, n0, wm, lane);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------- host
-template <int NGATE, bool WKM, int TAIL, int KS>
-static int chain_launch_ks(ChainBatch& b, int count, hipStream_t s) {
+template <int NGATE, bool WKM, int TAIL, int KS, int ND>
+static int chain_launch_ks(ChainBatch& b, hipStream_t s) {
     const ChainParams& p = b.d[0];
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)count), block(128 * KS);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(128 * KS);
     constexpr int BK = 16 * KS;
 #define CHAIN_CASE(NK_) \
-    case NK_: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, CHAIN_PF, NK_>), grid, block, 0, s, b); break;
+    case NK_: hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, CHAIN_PF, NK_, ND>), grid, block, 0, s, b); break;
     // The unrolled K loop is built for the 8-wave shape at K = Hp, 2Hp, 3Hp of Hp = 512 (hs 501: 8, 16
     // and 24 steps); deeper unrolls make hipcc hoist loads until the registers spill, and the
     // 4-wave shape needs its registers for co-residency: those run the runtime loop.
@@ -404,7 +424,7 @@ static int chain_launch_ks(ChainBatch& b, int count, hipStream_t s) {
         default: nk = 0; break;
         }
     }
-    if (nk == 0) hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, 1, 0>), grid, block, 0, s, b);
+    if (nk == 0) hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, 1, 0, ND>), grid, block, 0, s, b);
 #undef CHAIN_CASE
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
@@ -418,10 +438,10 @@ static int chain_launch(ChainBatch& b, int count, hipStream_t s) {
     }
     // DVAE_CHAIN_KS = 2 / 4 forces the workgroup shape (A/B runs)
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_KS"); return v ? atoi(v) : 0; }();
-    const long wgs = (long)b.d[0].tiles_x * b.d[0].tiles_y * count;
-    (void)wgs;
     const int ks = knob == 2 || knob == 4 ? knob : 4;
-    return ks == 2 ? chain_launch_ks<NGATE, WKM, TAIL, 2>(b, count, s) : chain_launch_ks<NGATE, WKM, TAIL, 4>(b, count, s);
+    if (count == 2)
+        return ks == 2 ? chain_launch_ks<NGATE, WKM, TAIL, 2, 2>(b, s) : chain_launch_ks<NGATE, WKM, TAIL, 4, 2>(b, s);
+    return ks == 2 ? chain_launch_ks<NGATE, WKM, TAIL, 2, 1>(b, s) : chain_launch_ks<NGATE, WKM, TAIL, 4, 1>(b, s);
 }
 
 static inline bool al16(const void* q) { return ((uintptr_t)q % 16) == 0; }
@@ -475,9 +495,14 @@ static int chain_fill(int op, const dvae_level_desc& v, int rows, int Hp, ChainP
 
 using namespace dvae;
 
+namespace dvae {
+int gated_bwd_gather_batch(const dvae_level_desc* lv, int count, int rows, int Hp, hipStream_t s);  // pointwise.hip
+}
+
 extern "C" int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows,
                                       int32_t Hp, void* stream) {
     DVAE_REQUIRE(levels && count >= 1 && count <= 2, "chain level batch: 1 or 2 levels per launch (got %d)", count);
+    if (op == DVAE_LEVEL_GATED_BWD_GATHER) return gated_bwd_gather_batch(levels, count, rows, Hp, (hipStream_t)stream);
     DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
     if (rows == 0) return DVAE_OK;
     ChainBatch b;

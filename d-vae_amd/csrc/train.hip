@@ -528,14 +528,14 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     } else if (merged) {
         DVAE_TRY(begin_dir(1, s));
         for (int step = n - 1; step >= 0; --step) {
-            dvae_level_desc gb[2] = {}, da[2] = {};
+            dvae_level_desc gb[2] = {}, da[2] = {}, ga[2] = {};
             for (int k = 0; k < 2; ++k) {
                 const int v = k == 0 ? step : n - 1 - step;
                 const long r0 = (long)v * B;
                 if (step < n - 1) {
-                    DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, (k == 0 ? bv.succ_off : bv.pred_off) + r0,
-                                                   k == 0 ? bv.succ_idx : bv.pred_idx, nullptr, nullptr, nullptr,
-                                                   w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
+                    ga[k].a = w.dagg[k]; ga[k].lda = Hp; ga[k].next_off = (k == 0 ? bv.succ_off : bv.pred_off) + r0;
+                    ga[k].idx = k == 0 ? bv.succ_idx : bv.pred_idx; ga[k].gm = w.gm[k] + r0 * 2 * Hp;
+                    ga[k].dx = w.dgm[k] + r0 * 2 * Hp;
                     gb[k].a = w.dgm[k] + r0 * 2 * Hp; gb[k].lda = 2 * Hp; gb[k].K = 2 * Hp; gb[k].w = pw + L.wgm[k];
                     gb[k].dx = w.dhs[k] + r0 * Hp; gb[k].ld_dx = Hp;
                     gb[k].gates = w.gates[k] + r0 * 3 * Hp; gb[k].ghn = w.ghn[k] + r0 * Hp;
@@ -550,7 +550,10 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                 da[k].a = w.dgh[k] + r0 * 3 * Hp; da[k].lda = 3 * Hp; da[k].K = 3 * Hp; da[k].w = pw + L.whh[k];
                 da[k].dx = w.dagg[k] + r0 * Hp; da[k].ld_dx = Hp;
             }
-            if (step < n - 1) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
+            if (step < n - 1) {
+                DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GATED_BWD_GATHER, ga, 2, B, Hp, s));
+                DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
+            }
             if (step > 0) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, da, 2, B, Hp, s));
         }
         DVAE_TRY(fork_side(side, s));

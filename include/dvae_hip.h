@@ -144,14 +144,17 @@ int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w
                        float* dgin, float* dhprev, int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream);
 
 /* The four level operations above as ONE launch over up to two independent levels of the same
- * shape (the two directions of the bidirectional encoder, models.py:724-727: as one grid the
- * second direction's workgroups start on a CU the moment the first's finish, where two launches
- * on two streams only serialize).  Fields a level operation does not use are ignored:
+ * shape (the two directions of the bidirectional encoder, models.py:724-727).  Fields a level
+ * operation does not use are ignored:
  *   GRU_FWD    a = hprev (lda), w = whh, gi_tab, types, bhn -> gates, ghn, hout (ld_hout)
  *   GATED_FWD  a = h (lda), w = wgm, gv_row -> gm, msg (ld_msg, cur_row0), next_agg (ld_agg, next_off, idx)
  *   DGRAD_ACC  a = dy (lda), K, w -> dx (ld_dx)
- *   GRU_BWD    a = dy (lda), K, w, gates, ghn, hprev (ld_hprev) -> dx = dh (ld_dx), dgh, dgin, dhprev (ld_dhprev) */
-enum { DVAE_LEVEL_GRU_FWD = 0, DVAE_LEVEL_GATED_FWD = 1, DVAE_LEVEL_DGRAD_ACC = 2, DVAE_LEVEL_GRU_BWD = 3 };
+ *   GRU_BWD    a = dy (lda), K, w, gates, ghn, hprev (ld_hprev) -> dx = dh (ld_dx), dgh, dgin, dhprev (ld_dhprev)
+ *   GATED_BWD_GATHER  dvae_gated_bwd_gather with one list: a = dagg (lda), next_off = off, idx, gm -> dx = dgm
+ * With two levels the products run as ONE grid whose workgroups contract their tile for both levels,
+ * alternating K steps (two accumulator sets): per-workgroup latencies are paid once. */
+enum { DVAE_LEVEL_GRU_FWD = 0, DVAE_LEVEL_GATED_FWD = 1, DVAE_LEVEL_DGRAD_ACC = 2, DVAE_LEVEL_GRU_BWD = 3,
+       DVAE_LEVEL_GATED_BWD_GATHER = 4 };
 typedef struct dvae_level_desc {
     const float* a;
     const float* w;
