@@ -40,7 +40,8 @@ class DvaeHipError(RuntimeError):
 class LevelDesc(C.Structure):
     """dvae_level_desc (include/dvae_hip.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("a", "w", "gi_tab", "types", "bhn", "gates", "ghn", "hout", "gv_row", "gm",
-                                          "msg", "next_agg", "next_off", "idx", "dx", "hprev", "dgh", "dgin", "dhprev")] + \
+                                          "msg", "next_agg", "next_off", "idx", "dx", "hprev", "dgh", "dgin", "dhprev",
+                                          "gather_src", "gather_src2", "off2", "idx2", "dgm_next")] + \
                [(n, C.c_int32) for n in ("lda", "K", "ld_hout", "ld_msg", "cur_row0", "ld_agg", "ld_dx", "ld_hprev",
                                          "ld_dhprev")]
 

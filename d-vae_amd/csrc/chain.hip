@@ -53,6 +53,11 @@ struct ChainParams {
     // backward: dX in/out and the outputs of the GRU backward tail
     float* C; int ldc;
     float* dgh; float* dgin; float* dhprev; int ld_dhprev;
+    // backward, dX += tail only (optional: dgm_out != NULL): the gate/mapper pointwise backward of the
+    // level processed NEXT, whose d msg rows are gather-sums of dX rows (this launch's and finished ones)
+    const float* gsrc; const int* goff; const int* gidx;    // dX of all levels (row pitch ldc), CSR of consumer slots
+    const float* gsrc2; const int* goff2; const int* gidx2; // optional second list
+    const float* gm_in; float* dgm_out;
 };
 
 __device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -149,6 +154,32 @@ __device__ __forceinline__ void gru_bwd_tail(const ChainParams& p, int row, int 
     cst4(p.dhprev + (long)row * p.ld_dhprev + col, dHP);
 }
 
+// d msg of the level processed next = gather-sum of its consumers' d agg rows (gated_bwd_gather_kernel's
+// arithmetic and summation order), consumed by the gate/mapper pointwise backward.  The consumers of
+// row r are slots of the same graph: the one this lane has just finished (slot cur_row0 + r, taken
+// from registers) and slots of levels finished by earlier launches.
+__device__ __forceinline__ void gather_bwd_tail(const ChainParams& p, int row, int col, float4 own) {
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = p.goff[row]; k < p.goff[row + 1]; ++k) {
+        const int s = p.gidx[k];
+        const float4 v = s == p.cur_row0 + row ? own : cld4(p.gsrc + (long)s * p.ldc + col);
+        d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+    }
+    if (p.goff2)
+        for (int k = p.goff2[row]; k < p.goff2[row + 1]; ++k) {
+            const float4 v = cld4(p.gsrc2 + (long)p.gidx2[k] * p.ldc + col);
+            d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+        }
+    const float* q = p.gm_in + (long)row * 2 * p.Hp;
+    const float4 g = cld4(q + col), m = cld4(q + p.Hp + col);
+    const float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                                  d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
+    const float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+    float* o = p.dgm_out + (long)row * 2 * p.Hp;
+    cst4(o + col, dg);
+    cst4(o + p.Hp + col, dm);
+}
+
 // ---------------------------------------------------------------------------------- epilogue
 // TAIL: 0 GRU forward (NGATE 3), 1 gate/mapper forward (NGATE 2), 2 dX += (NGATE 1), 3 dX += then GRU backward.
 // The wave of K slice KQ finishes 4 / KS register quads (quad q = columns 8 q + 4 (lane / 32) .. + 3):
@@ -202,6 +233,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&ac
             const float4 d = make_float4(c0.x + v[0].x, c0.y + v[0].y, c0.z + v[0].z, c0.w + v[0].w);
             cst4(c, d);
             if (TAIL == 3) gru_bwd_tail(p, row, col, d);
+            if (TAIL == 2 && p.dgm_out) gather_bwd_tail(p, row, col, d);
         }
     }
 }
@@ -484,6 +516,15 @@ static int chain_fill(int op, const dvae_level_desc& v, int rows, int Hp, ChainP
     case DVAE_LEVEL_DGRAD_ACC:
         DVAE_REQUIRE(v.dx && ldok(v.ld_dx, Hp) && al16(v.dx), "level dgrad: bad dx / ld_dx");
         p.C = v.dx; p.ldc = v.ld_dx;
+        if (op == DVAE_LEVEL_DGRAD_ACC && v.dgm_next) {
+            DVAE_REQUIRE(v.gather_src && v.next_off && v.idx && v.gm, "level dgrad: the fused gather needs gather_src, next_off, idx, gm");
+            DVAE_REQUIRE(!v.off2 || (v.gather_src2 && v.idx2), "level dgrad: second gather list incomplete");
+            DVAE_REQUIRE(al16(v.gather_src) && al16(v.gather_src2) && al16(v.gm) && al16(v.dgm_next),
+                         "level dgrad: gather buffers must be 16-byte aligned");
+            p.gsrc = v.gather_src; p.goff = v.next_off; p.gidx = v.idx; p.cur_row0 = v.cur_row0;
+            p.gsrc2 = v.gather_src2; p.goff2 = v.off2; p.gidx2 = v.idx2;
+            p.gm_in = v.gm; p.dgm_out = v.dgm_next;
+        }
         break;
     default:
         return set_err(DVAE_ERR_ARG, "chain level: unknown operation %d", op);
@@ -495,14 +536,9 @@ static int chain_fill(int op, const dvae_level_desc& v, int rows, int Hp, ChainP
 
 using namespace dvae;
 
-namespace dvae {
-int gated_bwd_gather_batch(const dvae_level_desc* lv, int count, int rows, int Hp, hipStream_t s);  // pointwise.hip
-}
-
 extern "C" int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows,
                                       int32_t Hp, void* stream) {
     DVAE_REQUIRE(levels && count >= 1 && count <= 2, "chain level batch: 1 or 2 levels per launch (got %d)", count);
-    if (op == DVAE_LEVEL_GATED_BWD_GATHER) return gated_bwd_gather_batch(levels, count, rows, Hp, (hipStream_t)stream);
     DVAE_REQUIRE(rows >= 0 && Hp > 0 && Hp % 32 == 0, "chain level: Hp must be a positive multiple of 32 (Hp=%d)", Hp);
     if (rows == 0) return DVAE_OK;
     ChainBatch b;

@@ -212,35 +212,6 @@ __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, 
     }
 }
 
-// the same for two independent levels in one launch (blockIdx.y): both encoder directions
-struct GatherBwd2 {
-    const float* dagg[2]; const int* off[2]; const int* idx[2]; const float* gm[2]; float* dgm[2];
-    int ld, rows, Hp;
-};
-__global__ void gated_bwd_gather2_kernel(GatherBwd2 a) {
-    const int y = blockIdx.y;
-    const float* __restrict__ dagg = a.dagg[y];
-    const int* __restrict__ off = a.off[y];
-    const int* __restrict__ idx = a.idx[y];
-    const float* __restrict__ gm = a.gm[y];
-    float* __restrict__ dgm = a.dgm[y];
-    const int w4 = a.Hp / 4;
-    const long total = (long)a.rows * w4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int r = (int)(i / w4), c = (int)(i % w4) * 4;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = off[r]; k < off[r + 1]; ++k) d = add4(d, ld4(dagg + (long)idx[k] * a.ld + c));
-        const float* p = gm + (long)r * 2 * a.Hp;
-        float4 g = ld4(p + c), m = ld4(p + a.Hp + c);
-        float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
-                                d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
-        float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-        float* o = dgm + (long)r * 2 * a.Hp;
-        st4(o + c, dg);
-        st4(o + a.Hp + c, dm);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // out[seg][c] += sum_{rows of seg} x[row][c].  grid: (width/4/64, chunks, segs)
 __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__ out, int ld_out,
@@ -390,26 +361,6 @@ extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
-
-// dvae_chain_level_batch(DVAE_LEVEL_GATED_BWD_GATHER, ...) of chain.hip ends here
-namespace dvae {
-int gated_bwd_gather_batch(const dvae_level_desc* lv, int count, int rows, int Hp, hipStream_t s) {
-    if (rows == 0) return DVAE_OK;
-    DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0, "gated_bwd_gather batch: bad Hp");
-    GatherBwd2 a = {};
-    a.ld = lv[0].lda; a.rows = rows; a.Hp = Hp;
-    for (int i = 0; i < 2; ++i) {
-        const dvae_level_desc& v = lv[i < count ? i : 0];
-        DVAE_REQUIRE(v.a && v.next_off && v.idx && v.gm && v.dx, "gated_bwd_gather batch: null pointer");
-        DVAE_REQUIRE(v.lda == a.ld && v.lda % 4 == 0, "gated_bwd_gather batch: the levels share one leading dimension");
-        a.dagg[i] = v.a; a.off[i] = v.next_off; a.idx[i] = v.idx; a.gm[i] = v.gm; a.dgm[i] = v.dx;
-    }
-    long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gated_bwd_gather2_kernel, dim3(ew_grid(total), count), dim3(256), 0, s, a);
-    DVAE_LAUNCH_CHECK();
-    return DVAE_OK;
-}
-}  // namespace dvae
 
 extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                                        int32_t seg_rows, int32_t width, void* stream) {

@@ -482,12 +482,12 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         const int v = k == 0 ? step : n - 1 - step;
         const long r0 = (long)v * B;
         float* dhs = w.dhs[k] + r0 * Hp;
-        if (step < n - 1) {
+        if (step < n - 1 && !fused) {
             DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr,
                                            w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
-            if (!fused)
-                DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+            DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
         }
+        // (fused: d gm of this level was written by the tail of the previous level's dgrad kernel, below)
         if (fused && step < n - 1)  // d h += d gm [Wg | Wm] and the GRU pointwise backward in one launch (chain.hip)
             DVAE_TRY(dvae_gru_level_bwd(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, 2 * Hp, pw + L.wgm[k], dhs, Hp,
                                         w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
@@ -496,10 +496,17 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp,
                                             Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B,
                                             Hp, s));
-        if (step > 0 && fused)
-            DVAE_TRY(dvae_level_dgrad_acc(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, 3 * Hp, pw + L.whh[k], w.dagg[k] + r0 * Hp, Hp, B,
-                                          Hp, s));
-        else if (step > 0)
+        if (step > 0 && fused) {
+            // d agg += d gh W_hh, then -- same launch -- the gate/mapper pointwise backward of the level
+            // processed next, whose d msg gathers d agg rows of this level (registers) and finished ones
+            const long r1 = (long)(k == 0 ? v - 1 : v + 1) * B;
+            dvae_level_desc da = {};
+            da.a = w.dgh[k] + r0 * 3 * Hp; da.lda = 3 * Hp; da.K = 3 * Hp; da.w = pw + L.whh[k];
+            da.dx = w.dagg[k] + r0 * Hp; da.ld_dx = Hp;
+            da.gather_src = w.dagg[k]; da.next_off = toff + r1; da.idx = tidx; da.cur_row0 = (int)r0;
+            da.gm = w.gm[k] + r1 * 2 * Hp; da.dgm_next = w.dgm[k] + r1 * 2 * Hp;
+            DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
+        } else if (step > 0)
             DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
                                3 * Hp, Hp, 1, s));
         return DVAE_OK;
@@ -528,14 +535,11 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     } else if (merged) {
         DVAE_TRY(begin_dir(1, s));
         for (int step = n - 1; step >= 0; --step) {
-            dvae_level_desc gb[2] = {}, da[2] = {}, ga[2] = {};
+            dvae_level_desc gb[2] = {}, da[2] = {};
             for (int k = 0; k < 2; ++k) {
                 const int v = k == 0 ? step : n - 1 - step;
                 const long r0 = (long)v * B;
                 if (step < n - 1) {
-                    ga[k].a = w.dagg[k]; ga[k].lda = Hp; ga[k].next_off = (k == 0 ? bv.succ_off : bv.pred_off) + r0;
-                    ga[k].idx = k == 0 ? bv.succ_idx : bv.pred_idx; ga[k].gm = w.gm[k] + r0 * 2 * Hp;
-                    ga[k].dx = w.dgm[k] + r0 * 2 * Hp;
                     gb[k].a = w.dgm[k] + r0 * 2 * Hp; gb[k].lda = 2 * Hp; gb[k].K = 2 * Hp; gb[k].w = pw + L.wgm[k];
                     gb[k].dx = w.dhs[k] + r0 * Hp; gb[k].ld_dx = Hp;
                     gb[k].gates = w.gates[k] + r0 * 3 * Hp; gb[k].ghn = w.ghn[k] + r0 * Hp;
@@ -549,11 +553,14 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                 }
                 da[k].a = w.dgh[k] + r0 * 3 * Hp; da[k].lda = 3 * Hp; da[k].K = 3 * Hp; da[k].w = pw + L.whh[k];
                 da[k].dx = w.dagg[k] + r0 * Hp; da[k].ld_dx = Hp;
+                if (step > 0) {  // fused tail: d gm of the level processed next
+                    const long r1 = (long)(k == 0 ? v - 1 : v + 1) * B;
+                    da[k].gather_src = w.dagg[k]; da[k].next_off = (k == 0 ? bv.succ_off : bv.pred_off) + r1;
+                    da[k].idx = k == 0 ? bv.succ_idx : bv.pred_idx; da[k].cur_row0 = (int)r0;
+                    da[k].gm = w.gm[k] + r1 * 2 * Hp; da[k].dgm_next = w.dgm[k] + r1 * 2 * Hp;
+                }
             }
-            if (step < n - 1) {
-                DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GATED_BWD_GATHER, ga, 2, B, Hp, s));
-                DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
-            }
+            if (step < n - 1) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
             if (step > 0) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, da, 2, B, Hp, s));
         }
         DVAE_TRY(fork_side(side, s));
@@ -770,14 +777,14 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         for (int v = n - 1; v >= 0; --v) {
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
-            if (v < n - 1) {
+            if (v < n - 1 && !fused) {
                 // d msg = consumers' d agg (successor slots + partial rows), used in registers
                 DVAE_TRY(dvae_gated_bwd_gather(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp,
                                                bv.pt_off + r0, bv.pt_idx, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B,
                                                Hp, s));
-                if (!fused)
-                    DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+                DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
             }
+            // (fused: d gm of vertex v was written by the tail of vertex v + 1's dgrad kernel, below)
             if (fused && v < n - 1)
                 DVAE_TRY(dvae_gru_level_bwd(w.dgm + r0 * 2 * Hp, 2 * Hp, 2 * Hp, pw + L.wgm[0], dst, Hp, w.gates + r0 * 3 * Hp,
                                             w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp,
@@ -785,9 +792,18 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             else
                 DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,
                                                 w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
-            if (fused)
-                DVAE_TRY(dvae_level_dgrad_acc(w.dgh + r0 * 3 * Hp, 3 * Hp, 3 * Hp, whh, w.dagg + r0 * Hp, Hp, B, Hp, s));
-            else
+            if (fused) {
+                dvae_level_desc da = {};
+                da.a = w.dgh + r0 * 3 * Hp; da.lda = 3 * Hp; da.K = 3 * Hp; da.w = whh;
+                da.dx = w.dagg + r0 * Hp; da.ld_dx = Hp;
+                if (v > 0) {  // same launch: d gm of vertex v - 1 from its consumers' d agg (successor slots + partial rows)
+                    const long r1 = r0 - B;
+                    da.gather_src = w.dagg; da.next_off = bv.succ_off + r1; da.idx = bv.succ_idx; da.cur_row0 = (int)r0;
+                    da.gather_src2 = w.dagg + p0 * Hp; da.off2 = bv.pt_off + r1; da.idx2 = bv.pt_idx;
+                    da.gm = w.gm + r1 * 2 * Hp; da.dgm_next = w.dgm + r1 * 2 * Hp;
+                }
+                DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
+            } else
                 DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
         }
     }

@@ -148,13 +148,14 @@ int dvae_gru_level_bwd(const float* dy, int32_t ld_dy, int32_t K, const float* w
  * operation does not use are ignored:
  *   GRU_FWD    a = hprev (lda), w = whh, gi_tab, types, bhn -> gates, ghn, hout (ld_hout)
  *   GATED_FWD  a = h (lda), w = wgm, gv_row -> gm, msg (ld_msg, cur_row0), next_agg (ld_agg, next_off, idx)
- *   DGRAD_ACC  a = dy (lda), K, w -> dx (ld_dx)
+ *   DGRAD_ACC  a = dy (lda), K, w -> dx (ld_dx); optionally (dgm_next != NULL) followed, in the same launch,
+ *              by dvae_gated_bwd_gather for the level processed NEXT, whose consumers are dx rows of this
+ *              launch (slot cur_row0 + r: taken from registers) and finished ones: gather_src (all levels'
+ *              dx, pitch ld_dx), next_off, idx (+ optional gather_src2, off2, idx2), gm -> dgm_next
  *   GRU_BWD    a = dy (lda), K, w, gates, ghn, hprev (ld_hprev) -> dx = dh (ld_dx), dgh, dgin, dhprev (ld_dhprev)
- *   GATED_BWD_GATHER  dvae_gated_bwd_gather with one list: a = dagg (lda), next_off = off, idx, gm -> dx = dgm
  * With two levels the products run as ONE grid whose workgroups contract their tile for both levels,
  * alternating K steps (two accumulator sets): per-workgroup latencies are paid once. */
-enum { DVAE_LEVEL_GRU_FWD = 0, DVAE_LEVEL_GATED_FWD = 1, DVAE_LEVEL_DGRAD_ACC = 2, DVAE_LEVEL_GRU_BWD = 3,
-       DVAE_LEVEL_GATED_BWD_GATHER = 4 };
+enum { DVAE_LEVEL_GRU_FWD = 0, DVAE_LEVEL_GATED_FWD = 1, DVAE_LEVEL_DGRAD_ACC = 2, DVAE_LEVEL_GRU_BWD = 3 };
 typedef struct dvae_level_desc {
     const float* a;
     const float* w;
@@ -175,6 +176,11 @@ typedef struct dvae_level_desc {
     float* dgh;
     float* dgin;
     float* dhprev;
+    const float* gather_src;
+    const float* gather_src2;
+    const int32_t* off2;
+    const int32_t* idx2;
+    float* dgm_next;
     int32_t lda, K, ld_hout, ld_msg, cur_row0, ld_agg, ld_dx, ld_hprev, ld_dhprev;
 } dvae_level_desc;
 int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows, int32_t Hp,

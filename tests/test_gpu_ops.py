@@ -640,3 +640,52 @@ def test_chain_level_batch_two_levels_equals_two_launches():
             assert torch.equal(x, y)
     # more than two levels per launch is refused
     assert lib.dvae_chain_level_batch(0, descs, 3, rows, Hp, _s()) != 0
+
+
+@pytest.mark.parametrize("two_lists", [False, True])
+def test_level_dgrad_acc_with_fused_gather_tail(two_lists):
+    """DGRAD_ACC with dgm_next set == dvae_level_dgrad_acc followed by dvae_gated_bwd_gather for the
+    level processed next, bit for bit (the tail sums the consumers in list order and takes this
+    launch's own row from registers: the value it has just stored)."""
+    g = torch.Generator().manual_seed(91 + two_lists)
+    B, Hp, levels, cur = 100, 64, 4, 2          # current level 2; the next one processed is level 1
+    K = 3 * Hp
+    lib = L.load()
+    dagg0 = torch.randn(levels * B, Hp, generator=g).cuda()
+    dgh = torch.randn(B, K, generator=g).cuda()
+    whh = (torch.randn(K, Hp, generator=g) / K ** 0.5).cuda()
+    gm = torch.rand(B, 2 * Hp, generator=g).cuda()
+    # consumers of level-1 rows: slots of the same graph in levels 2 (current) and 3 (finished)
+    off, idx = [0], []
+    for b in range(B):
+        idx += [u * B + b for u in (2, 3) if torch.rand((), generator=g) < 0.7]
+        off.append(len(idx))
+    off_d = torch.tensor(off, dtype=torch.int32).cuda()
+    idx_d = torch.tensor(idx + [0], dtype=torch.int32).cuda()
+    dagg2 = torch.randn(30, Hp, generator=g).cuda()
+    lens2 = torch.randint(0, 3, (B,), generator=g)
+    off2 = torch.zeros(B + 1, dtype=torch.int32)
+    off2[1:] = lens2.cumsum(0)
+    off2_d = off2.cuda()
+    idx2_d = torch.randint(0, 30, (int(off2[-1]) + 1,), generator=g).int().cuda()
+    # reference: two launches
+    dagg_ref = dagg0.clone()
+    L.check(lib.dvae_level_dgrad_acc(dgh.data_ptr(), K, K, whh.data_ptr(), dagg_ref[cur * B:].data_ptr(), Hp, B, Hp, _s()))
+    dgm_ref = torch.full((B, 2 * Hp), float("nan")).cuda()
+    L.check(lib.dvae_gated_bwd_gather(dagg_ref.data_ptr(), Hp, off_d.data_ptr(), idx_d.data_ptr(),
+                                      dagg2.data_ptr() if two_lists else None, off2_d.data_ptr() if two_lists else None,
+                                      idx2_d.data_ptr() if two_lists else None, gm.data_ptr(), dgm_ref.data_ptr(), B, Hp, _s()))
+    # fused
+    dagg = dagg0.clone()
+    dgm = torch.full((B, 2 * Hp), float("nan")).cuda()
+    d = L.LevelDesc()
+    d.a, d.lda, d.K, d.w = dgh.data_ptr(), K, K, whh.data_ptr()
+    d.dx, d.ld_dx = dagg[cur * B:].data_ptr(), Hp
+    d.gather_src, d.next_off, d.idx, d.cur_row0 = dagg.data_ptr(), off_d.data_ptr(), idx_d.data_ptr(), cur * B
+    if two_lists:
+        d.gather_src2, d.off2, d.idx2 = dagg2.data_ptr(), off2_d.data_ptr(), idx2_d.data_ptr()
+    d.gm, d.dgm_next = gm.data_ptr(), dgm.data_ptr()
+    L.check(lib.dvae_chain_level_batch(2, C.byref(d), 1, B, Hp, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(dagg, dagg_ref)
+    assert torch.isfinite(dgm).all() and torch.equal(dgm, dgm_ref)
