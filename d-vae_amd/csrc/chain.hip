@@ -4,8 +4,11 @@
 //
 //   chain_kernel<3, false, 0>:  (r, z, n, W_hn h + b_hn, h') = GRUCell tail of  h_prev W_hh^T
 //   chain_kernel<2, false, 1>:  (g, m, msg = g*m, next level's predecessor sum) of  h [Wg | Wm]^T
-//   chain_kernel<1, true, 2>:   dX += dY W                          (d agg += d gh W_hh)
+//   chain_kernel<1, true, 2>:   dX += dY W   (d agg += d gh W_hh), then optionally the gate/mapper pointwise
+//                               backward of the level processed next (its d msg gathers dX rows)
 //   chain_kernel<1, true, 3>:   d h = dX + dY W, then the GRUCell pointwise backward of d h
+// A forward level is 2 launches (GEMM + pointwise + GEMM + pointwise/gather before), a backward level 2
+// (gather + split-K GEMM + pointwise + split-K GEMM before).
 //
 // Why kernels of their own instead of epilogues of gemm_f32_kernel: the forward tails need the r, z
 // and n (or g and m) pre-activations of one (row, hidden unit) in ONE lane, i.e. columns j, Hp + j,
@@ -29,11 +32,10 @@
 namespace dvae {
 
 // Two shapes of workgroup, template parameter KS = number of K slices of a step:
-//   KS = 4: 512 threads, 64-deep K steps, 87 KB LDS (GRU) -- two waves per SIMD inside ONE workgroup; the
-//           choice when the grid is a single round of the chip (the decoder's chain: 256 workgroups)
-//   KS = 2: 256 threads, 32-deep K steps, 46 KB LDS -- two or three workgroups share a CU, so one's
-//           cold prologue and epilogue hide under another's K loop; the choice when the grid has at
-//           least two workgroups per CU (both encoder directions in one grid, large batches)
+//   KS = 4: 512 threads, 64-deep K steps, 87 KB LDS (GRU) -- two waves per SIMD inside ONE workgroup: the default
+//   KS = 2: 256 threads, 32-deep K steps, 46 KB LDS -- two or three workgroups can share a CU; measured
+//           slower (forward level 42 vs 36 us alone, and no gain with two directions co-resident:
+//           workgroups launched together run in lockstep); kept behind DVAE_CHAIN_KS=2 and tested
 // Either way a wave contracts 16 k (two groups of 8) of each step for its 32 rows and all gates.
 constexpr int CBM = 64;        // rows per workgroup
 constexpr int CBH = 32;        // hidden units (output columns per gate) per workgroup

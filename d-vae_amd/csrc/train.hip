@@ -599,7 +599,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
 
     // level-major batches (every graph full size: all of the reference's data sets) run the
     // per-level predictor products beside the chain
-    const bool by_level = !d.bn && c->level_major != 0;
+    static const int by_level_knob = [] { const char* v = getenv("DVAE_BY_LEVEL"); return v ? atoi(v) : 1; }();
+    const bool by_level = !d.bn && c->level_major != 0 && by_level_knob != 0;
     Side* side = nullptr;
     if (by_level) DVAE_TRY(side_for_current_device(&side));
     DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
