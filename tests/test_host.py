@@ -158,3 +158,30 @@ def test_balanced_shard_bounds_partitions_and_evens_out_pair_work():
     ceil = worst([dvae_amd.shard_bounds(len(nv), 4, r) for r in range(4)])
     bal = worst([dvae_amd.balanced_shard_bounds(nv, 4, r) for r in range(4)])
     assert bal < 1.1 < ceil
+
+
+def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
+    """include/dvae_hip.h compiles as plain C (gcc, the language a foreign-function binding sees), and
+    every struct d-vae_amd/_lib.py mirrors with ctypes has the header's size and field offsets."""
+    import ctypes
+    import subprocess
+    L = dvae_amd._lib
+    structs = {"dvae_model_desc": L.ModelDesc, "dvae_batch_counts": L.BatchCounts, "dvae_gemm_desc": L.GemmDesc,
+               "dvae_level_desc": L.LevelDesc}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "dvae_hip.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
