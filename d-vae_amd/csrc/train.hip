@@ -460,7 +460,10 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
         DVAE_TRY(dvae_scatter_rows_add_f32(w.dhs[k], Hp, dhg + (k ? Hp : 0), ld_dhg, k ? bv.hgb_off : bv.hgf_off,
                                            k ? bv.hgb_idx : bv.hgf_idx, B, Hp, s));
-        if (!d.bn) DVAE_HIP(hipMemsetAsync(w.dgm[k], 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
+        // d gm: every level's rows are written whole by the chain below except the level that sends no
+        // message (the last vertex of the pass): only those rows need the zeros
+        if (!d.bn)
+            DVAE_HIP(hipMemsetAsync(w.dgm[k] + (size_t)(k == 0 ? n - 1 : 0) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
         return DVAE_OK;
     };
     auto run_dir_bn = [&](int k, hipStream_t s) -> int {
@@ -774,7 +777,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(dvae_gru_pointwise_bwd(w.dst + p0 * Hp, Hp, w.gates + p0 * 3 * Hp, w.ghn + p0 * Hp, w.agg + p0 * Hp, Hp,
                                         w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp, s));
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
-        DVAE_HIP(hipMemsetAsync(w.dgm, 0, sizeof(float) * (size_t)nB * 2 * Hp, s));
+        // (only the last vertex's rows of d gm are not written by the chain below)
+        DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
         for (int v = n - 1; v >= 0; --v) {
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
