@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32),
-                ("act", C.c_int32), ("accumulate", C.c_int32)]
+                ("act", C.c_int32), ("accumulate", C.c_int32), ("relu_mask", C.c_void_p)]
 
 
 class DvaeHipError(RuntimeError):

@@ -374,6 +374,7 @@ int gemm_check(const dvae_gemm_desc& d, int kmult) {
     else DVAE_REQUIRE(d.N % 4 == 0 && d.ldb >= d.N, "gemm: K-major B needs N %% 4 == 0 (N=%d ldb=%d)", d.N, d.ldb);
     DVAE_REQUIRE(d.ldc >= d.N, "gemm: ldc < N");
     DVAE_REQUIRE(d.act >= 0 && d.act <= 2, "gemm: unknown activation %d", d.act);
+    DVAE_REQUIRE(!d.relu_mask || !d.accumulate, "gemm: relu_mask cannot be combined with accumulate");
     return DVAE_OK;
 }
 
@@ -386,7 +387,7 @@ int gemm_k_chunk(const dvae_gemm_desc& d, int bk) {
     if (d.a_kmajor) rowb = d.lda * 4.0;
     if (d.b_kmajor && !d.b_rows && d.ldb * 4.0 > rowb) rowb = d.ldb * 4.0;
     if (rowb == 0.0 || (double)d.K * rowb < lim) return d.K > 0 ? d.K : 1;
-    DVAE_REQUIRE(d.act == 0, "gemm: a chunked contraction cannot apply an activation");
+    DVAE_REQUIRE(d.act == 0 && !d.relu_mask, "gemm: a chunked contraction cannot apply an activation or a mask");
     const int kc = (int)(lim / rowb) / bk * bk;
     DVAE_REQUIRE(kc >= bk, "gemm: leading dimension too large for a K-major operand");
     return kc;
@@ -404,6 +405,7 @@ bool gemm_next_chunk(const dvae_gemm_desc& d, int kc, int& k0, dvae_gemm_desc& s
         sub.B = d.B + k0;
     }
     if (k0 > 0) { sub.accumulate = 1; sub.bias = nullptr; }
+    // (a masked product is never chunked: gemm_k_chunk refuses an activation, and the mask is applied with it)
     k0 += sub.K;
     return true;
 }
@@ -438,7 +440,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C;
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;
-    p.bias = d.bias; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+    p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
     p.split_k = 1; p.k_per_split = 0;
     if (d.K == 0) {

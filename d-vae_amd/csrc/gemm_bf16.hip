@@ -272,7 +272,7 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C;
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;
-    p.bias = d.bias; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+    p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
     p.split_k = 1; p.k_per_split = 0;
     // Tile / split-K choice: as for the fp32 kernel.  A bf16 K step is 16x cheaper on the matrix

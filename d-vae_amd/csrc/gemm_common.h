@@ -14,6 +14,7 @@ struct GemmParams {
     const float* A; const float* B; float* C;
     const int* a_rows; const int* b_rows; const int* c_rows;
     const float* bias;
+    const float* relu_mask;  // nullable: C = mask > 0 ? value : 0, mask laid out like C
     int lda, ldb, ldc;
     int M, N, K;
     int act;         // 0 none, 1 relu, 2 tanh
@@ -82,6 +83,7 @@ __device__ __forceinline__ void store_acc(const GemmParams& p, f32x16 (&acc)[TM]
                             float v = acc[i][j][r] + bv;
                             if (p.act == 1) v = fmaxf(v, 0.f);
                             else if (p.act == 2) v = tanhf(v);
+                            if (p.relu_mask) v = p.relu_mask[crow * p.ldc + col] > 0.f ? v : 0.f;
                             if (p.accumulate) v += *dst;
                             *dst = v;
                         }
@@ -112,6 +114,11 @@ __device__ __forceinline__ void store_acc(const GemmParams& p, f32x16 (&acc)[TM]
                     } else if (p.act == 2) {
                         v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
                     }
+                    if (p.relu_mask) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.relu_mask + crow * p.ldc + col);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
                     float4* dst = reinterpret_cast<float4*>(drow + col);
                     if (p.accumulate) {
                         const float4 o = *dst;
@@ -127,7 +134,7 @@ __device__ __forceinline__ void store_acc(const GemmParams& p, f32x16 (&acc)[TM]
 // can this product use the 16-byte (SWAP) epilogue?
 inline bool gemm_vec_epilogue_ok(const GemmParams& p) {
     return p.split_k <= 1 && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0 &&
-           (p.bias == nullptr || ((uintptr_t)p.bias % 16) == 0);
+           (p.bias == nullptr || ((uintptr_t)p.bias % 16) == 0) && ((uintptr_t)p.relu_mask % 16) == 0;
 }
 
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16.hip

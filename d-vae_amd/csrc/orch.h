@@ -22,11 +22,12 @@ static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, in
     return run_gemm(g, s);
 }
 // dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)
+// relu_out (nullable, laid out like dX): the layer's input was relu_out = ReLU(.), and dX is masked by relu_out > 0
 static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
-                     int N, int K, int acc, hipStream_t s) {
+                     int N, int K, int acc, hipStream_t s, const float* relu_out = nullptr) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
-    g.M = M; g.N = K; g.K = N; g.accumulate = acc;
+    g.M = M; g.N = K; g.K = N; g.accumulate = acc; g.relu_mask = relu_out;
     return run_gemm(g, s);
 }
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)

@@ -59,11 +59,6 @@ __global__ void add_inplace_kernel(float* d, const float* a, long n) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i < n) d[i] += a[i];
 }
-// d = y > 0 ? d : 0
-__global__ void relu_bwd_kernel(float* d, const float* y, long n) {
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i < n) d[i] = y[i] > 0.f ? d[i] : 0.f;
-}
 __global__ void scaled_copy_kernel(float* d, const float* x, const float* s, long n) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i < n) d[i] = x[i] * s[0];
@@ -736,8 +731,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
     // vertex-type predictor, data path (main stream)
     EW(scaled_copy_kernel, (long)c->R * d.Tp, w.dlogits_s, w.dlogits, g_res, (long)c->R * d.Tp);
-    DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s));
-    EW(relu_bwd_kernel, (long)c->R * d.HVp, w.dv1, w.v1, (long)c->R * d.HVp);
+    // (the ReLU backward of add_vertex's hidden layer is the product's epilogue: masked by v1 > 0)
+    DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s, w.v1));
     DVAE_TRY(fork_side(side, s));
     {
         hipStream_t s2 = side->stream;

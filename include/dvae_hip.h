@@ -56,6 +56,8 @@ typedef struct dvae_gemm_desc {
     int32_t a_kmajor, b_kmajor;
     int32_t act;
     int32_t accumulate;
+    const float* relu_mask; /* nullable, [M][ldc] laid out like C: C = mask > 0 ? result : 0 (the backward of a
+                               ReLU whose output is `mask`, models.py:566 add_vertex; not with accumulate) */
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
 /* The same product with the operands rounded to bf16 (round to nearest even) on

@@ -689,3 +689,29 @@ def test_level_dgrad_acc_with_fused_gather_tail(two_lists):
     torch.cuda.synchronize()
     assert torch.equal(dagg, dagg_ref)
     assert torch.isfinite(dgm).all() and torch.equal(dgm, dgm_ref)
+
+
+@pytest.mark.parametrize("M,N,K,bf16", [(700, 1024, 32, False), (50, 40, 64, False), (300, 256, 32, True)])
+def test_gemm_relu_mask_epilogue(M, N, K, bf16):
+    """dgrad with relu_mask: dX = (dY W) where mask > 0 else 0 (ReLU backward as the product's epilogue)."""
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, K, generator=g).cuda()
+    W = torch.randn(K, N, generator=g).cuda()             # K-major B operand: [K][N]
+    mask = torch.randn(M, N, generator=g).clamp(min=0).cuda()  # a ReLU output: zeros and positives
+    out = torch.full((M, N), float("nan")).cuda()
+    d = L.GemmDesc()
+    d.A, d.B, d.C = dY.data_ptr(), W.data_ptr(), out.data_ptr()
+    d.lda, d.ldb, d.ldc = K, N, N
+    d.M, d.N, d.K = M, N, K
+    d.b_kmajor = 1
+    d.relu_mask = mask.data_ptr()
+    fn = L.load().dvae_gemm_bf16 if bf16 else L.load().dvae_gemm_f32
+    L.check(fn(C.byref(d), _s()), "gemm")
+    torch.cuda.synchronize()
+    ref = torch.where(mask > 0, (dY.double() @ W.double()).float(), torch.zeros((), device="cuda"))
+    tol = 0.3 if bf16 else 1e-4
+    assert torch.isfinite(out).all() and (out - ref).abs().max() < tol
+    assert (out[mask <= 0] == 0).all()
+    # not combinable with accumulate
+    d.accumulate = 1
+    assert fn(C.byref(d), _s()) != 0
