@@ -238,10 +238,13 @@ static int check_batch(const Dims& d, const dvae_batch_counts* c) {
 }
 
 // weight gradients shared by every GRU pass: dWhh, d gi_tab, d bhn
+// (rows [zero_lo, zero_hi) have h_prev = 0 -- the first level of an encoder pass -- and are left out of dWhh)
 static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
-                      const float* agg, const float* xoh, int rows, hipStream_t s) {
+                      const float* agg, const float* xoh, int rows, hipStream_t s, int zero_lo = 0, int zero_hi = 0) {
     const int Hp = d.Hp;
-    DVAE_TRY(lin_wgrad(dgh, 3 * Hp, agg, Hp, nullptr, pg + L.whh[g], Hp, rows, 3 * Hp, Hp, s));
+    const int lo = zero_lo == 0 ? zero_hi : 0, hi = zero_hi == rows && zero_lo > 0 ? zero_lo : rows;  // a prefix or a suffix
+    DVAE_TRY(lin_wgrad(dgh + (size_t)lo * 3 * Hp, 3 * Hp, agg + (size_t)lo * Hp, Hp, nullptr, pg + L.whh[g], Hp, hi - lo,
+                       3 * Hp, Hp, s));
     // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin
     DVAE_TRY(lin_wgrad(xoh, d.Tp, dgh, 3 * Hp, nullptr, pg + L.gi[g], 3 * Hp, rows, d.Tp, 2 * Hp, s));
     DVAE_TRY(lin_wgrad(xoh, d.Tp, dgin, Hp, nullptr, pg + L.gi[g] + 2 * Hp, 3 * Hp, rows, d.Tp, Hp, s));
@@ -514,7 +517,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             DVAE_TRY(lin_wgrad(w.dgm[k], 2 * Hp, w.hs[k], Hp, nullptr, pg + L.wgm[k], Hp, nB, 2 * Hp, Hp, s));
             DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
-        DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s));
+        // DVAE: the pass's first level (vertex 0 forward, vertex n-1 backward) has no predecessors, h_prev = 0
+        const int z_lo = d.bn ? 0 : (k == 0 ? 0 : nB - B), z_hi = d.bn ? 0 : (k == 0 ? B : nB);
+        DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s, z_lo, z_hi));
         return DVAE_OK;
     };
     // as in the forward pass: two streams, enqueued level by level in turn
