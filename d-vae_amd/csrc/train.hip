@@ -514,7 +514,10 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     };
     auto end_dir = [&](int k, hipStream_t s) -> int {
         if (!d.bn) {
-            DVAE_TRY(lin_wgrad(w.dgm[k], 2 * Hp, w.hs[k], Hp, nullptr, pg + L.wgm[k], Hp, nB, 2 * Hp, Hp, s));
+            // (d gm of the pass's last vertex is zero -- no message leaves it: those B rows are left out)
+            const size_t o = k == 0 ? 0 : (size_t)B;
+            DVAE_TRY(lin_wgrad(w.dgm[k] + o * 2 * Hp, 2 * Hp, w.hs[k] + o * Hp, Hp, nullptr, pg + L.wgm[k], Hp, nB - B,
+                               2 * Hp, Hp, s));
             DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
         // DVAE: the pass's first level (vertex 0 forward, vertex n-1 backward) has no predecessors, h_prev = 0
@@ -823,7 +826,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(lin_dgrad(w.dagg, Hp, pw + L.fc3, d.NZp, w.dz, d.NZp, nullptr, B, Hp, d.NZp, 0, s));
     DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
     if (!d.bn) {
-        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB, 2 * Hp, Hp, s));
+        // (d gm of the last vertex is zero: left out)
+        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
     }
     DVAE_TRY(join_side(side, s));
