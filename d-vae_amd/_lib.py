@@ -71,6 +71,8 @@ SIGNATURES = {
     "dvae_level_dgrad_acc": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
     "dvae_chain_level_batch": (_I, [_I, C.POINTER(LevelDesc), _I, _I, _I, _P]),
     "dvae_gated_level_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
+    "dvae_type_csr": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "dvae_type_colsum": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "dvae_segment_colsum_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "dvae_pair_mask_words": (C.c_int64, [_I, _I]),
     "dvae_pair_bce_fwd": (_I, [_P] * 14 + [_I, _I, _I, _P]),

@@ -249,6 +249,83 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Rows sorted by vertex type (counting sort, ONE workgroup): off[T + 1], idx[na + nb].  The rows
+// are those of two type arrays laid end to end (slots, then the decoder's partial rows).
+__global__ __launch_bounds__(1024) void type_csr_kernel(const int* __restrict__ ta, int na, const int* __restrict__ tb,
+                                                         int nb, int T, int* __restrict__ off, int* __restrict__ idx) {
+    __shared__ int hist[33], cur[32];
+    const int tid = threadIdx.x, n = na + nb;
+    if (tid < 33) hist[tid] = 0;
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) {
+        const int t = r < na ? ta[r] : tb[r - na];
+        if (t >= 0 && t < T) atomicAdd(&hist[t], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int t = 0; t < T; ++t) {
+            const int c = hist[t];
+            off[t] = s;
+            cur[t] = s;
+            s += c;
+        }
+        off[T] = s;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) {
+        const int t = r < na ? ta[r] : tb[r - na];
+        if (t >= 0 && t < T) idx[atomicAdd(&cur[t], 1)] = r;
+    }
+}
+
+// Per-type column sums of the virtual row [dgh (3Hp) | dgin (Hp)] -- everything the GRU's input-side
+// and bias gradients need from ONE read of the two arrays:
+//   gi[t][0:2Hp]   += sum over rows of type t of dgh[:, 0:2Hp]      (d pre_r, d pre_z)
+//   bhn[0:Hp]      += sum over all rows of dgh[:, 2Hp:3Hp]          (d (W_hn h + b_hn))
+//   gi[t][2Hp:3Hp] += sum over rows of type t of dgin               (d pre_n)
+// grid (ceil(Hp / 64) column blocks of 64 float4, row chunks, T); partial sums are added with atomics.
+__global__ __launch_bounds__(256) void type_colsum_kernel(const float* __restrict__ dgh, const float* __restrict__ dgin,
+                                                          const int* __restrict__ off, const int* __restrict__ idx,
+                                                          float* __restrict__ gi, float* __restrict__ bhn, int Hp,
+                                                          int rows_per_chunk) {
+    __shared__ float4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.z;
+    const int k0 = off[t] + blockIdx.y * rows_per_chunk;
+    const int k1 = min(off[t + 1], k0 + rows_per_chunk);
+    if (k0 >= k1) return;  // (uniform over the workgroup)
+    const int c4 = blockIdx.x * 64 + tx;  // float4 column of the 4Hp-wide virtual row
+    const bool on = c4 < Hp;
+    const int col = c4 * 4;
+    const float* base = col < 3 * Hp ? dgh + col : dgin + (col - 3 * Hp);
+    const long ld = col < 3 * Hp ? 3 * Hp : Hp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+        float4 a1 = acc, a2 = acc, a3 = acc;
+        int k = k0 + ty;
+        for (; k + 12 < k1; k += 16) {  // four independent row streams per thread
+            float4 v0 = ld4(base + idx[k] * ld), v1 = ld4(base + idx[k + 4] * ld);
+            float4 v2 = ld4(base + idx[k + 8] * ld), v3 = ld4(base + idx[k + 12] * ld);
+            acc = add4(acc, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
+        }
+        for (; k < k1; k += 4) acc = add4(acc, ld4(base + idx[k] * ld));
+        acc = add4(add4(acc, a1), add4(a2, a3));
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && on) {
+        acc = add4(add4(red[0][tx], red[1][tx]), add4(red[2][tx], red[3][tx]));
+        float* o = col < 2 * Hp ? gi + (long)t * 3 * Hp + col
+                 : (col < 3 * Hp ? bhn + (col - 2 * Hp) : gi + (long)t * 3 * Hp + 2 * Hp + (col - 3 * Hp));
+        atomicAdd(o + 0, acc.x);
+        atomicAdd(o + 1, acc.y);
+        atomicAdd(o + 2, acc.z);
+        atomicAdd(o + 3, acc.w);
+    }
+}
+
 static inline int ew_grid(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -358,6 +435,32 @@ extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_
     long total = (long)rows * (Hp / 4);
     hipLaunchKernelGGL(gated_bwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dagg, ld, off,
                        idx, dagg2, off2, idx2, gm, dgm, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_type_csr(const int32_t* types_a, int32_t na, const int32_t* types_b, int32_t nb, int32_t T,
+                             int32_t* off, int32_t* idx, void* stream) {
+    DVAE_REQUIRE(na >= 0 && nb >= 0 && T >= 1 && T <= 32, "type_csr: bad sizes (T=%d)", T);
+    DVAE_REQUIRE(off && idx && (na == 0 || types_a) && (nb == 0 || types_b), "type_csr: null pointer");
+    hipLaunchKernelGGL(type_csr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, types_a, na, types_b, nb, T, off, idx);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
+extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T,
+                                float* gi, float* bhn, int32_t rows, int32_t Hp, void* stream) {
+    if (rows == 0) return DVAE_OK;
+    DVAE_REQUIRE(dgh && dgin && off && idx && gi && bhn, "type_colsum: null pointer");
+    DVAE_REQUIRE(T >= 1 && T <= 32 && Hp > 0 && Hp % 4 == 0, "type_colsum: bad sizes (T=%d Hp=%d)", T, Hp);
+    const int xblocks = cdiv(Hp, 64);
+    // row chunks: the lists' lengths are not known on the host, so every type gets chunks for `rows`
+    // rows and the surplus workgroups leave at once; bounded to ~16 k workgroups per launch
+    long rpc = ((long)rows * T * xblocks + 16383) / 16384;
+    if (rpc < 64) rpc = 64;
+    const int chunks = cdiv(rows, rpc);
+    hipLaunchKernelGGL(type_colsum_kernel, dim3(xblocks, chunks, T), dim3(256), 0, (hipStream_t)stream, dgh, dgin, off, idx,
+                       gi, bhn, Hp, (int)rpc);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

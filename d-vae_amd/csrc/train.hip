@@ -18,13 +18,6 @@
 namespace dvae {
 
 // ------------------------------------------------------------------ small kernels
-__global__ void onehot_kernel(float* x, const int* types, int rows, int Tp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * Tp) return;
-    int r = i / Tp, t = i % Tp;
-    x[i] = types[r] == t ? 1.f : 0.f;
-}
-// cnt[r][t] = number of list entries of row r equal to t
 __global__ void count_kernel(float* cnt, const int* off, const int* idx, int rows, int Tp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * Tp) return;
@@ -136,7 +129,7 @@ static int join_side(Side* sd, hipStream_t main) {
 struct EncWs {
     float *agg[2], *gates[2], *ghn[2], *hs[2], *gm[2], *msg[2];
     float *hg, *hgu, *out12;
-    float* xoh;  // one-hot of vertex types [nB][Tp]
+    float* xoh;  // [nB][Tp] floats, used as int storage: rows sorted by vertex type (off[T+1] at 0, idx[nB] at 40)
     // backward
     float *dhs[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
     float *d12, *dhgu, *dhg;
@@ -245,10 +238,10 @@ static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, co
     const int lo = zero_lo == 0 ? zero_hi : 0, hi = zero_hi == rows && zero_lo > 0 ? zero_lo : rows;  // a prefix or a suffix
     DVAE_TRY(lin_wgrad(dgh + (size_t)lo * 3 * Hp, 3 * Hp, agg + (size_t)lo * Hp, Hp, nullptr, pg + L.whh[g], Hp, hi - lo,
                        3 * Hp, Hp, s));
-    // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin
-    DVAE_TRY(lin_wgrad(xoh, d.Tp, dgh, 3 * Hp, nullptr, pg + L.gi[g], 3 * Hp, rows, d.Tp, 2 * Hp, s));
-    DVAE_TRY(lin_wgrad(xoh, d.Tp, dgin, Hp, nullptr, pg + L.gi[g] + 2 * Hp, 3 * Hp, rows, d.Tp, Hp, s));
-    DVAE_TRY(dvae_segment_colsum_f32(pg + L.bhn[g], Hp, dgh + 2 * Hp, 3 * Hp, rows, rows, Hp, s));
+    // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin; d bhn = column sum of
+    // dgh's n block: one sweep over the rows sorted by type (instead of two one-hot products and a column sum)
+    const int* tcsr = reinterpret_cast<const int*>(xoh);
+    DVAE_TRY(dvae_type_colsum(dgh, dgin, tcsr, tcsr + 40, d.T, pg + L.gi[g], pg + L.bhn[g], rows, Hp, s));
     return DVAE_OK;
 }
 
@@ -452,7 +445,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         dhg = w.dhg;
         ld_dhg = 2 * Hp;
     }
-    EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
+    // rows sorted by vertex type, for the GRUs' input-side gradients (off at xoh[0..T], idx from xoh[40])
+    DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s));
 
     auto begin_dir = [&](int k, hipStream_t s) -> int {
         DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
@@ -764,8 +758,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(dvae_gather_sum_f32(w.dst, Hp, w.dvs, Hp, bv.vst_off, bv.vst_idx, nB, Hp, 1, s));
 
     // ---- states --------------------------------------------------------------------
-    EW(onehot_kernel, (long)nB * d.Tp, w.xoh, bv.types, nB, d.Tp);
-    EW(onehot_kernel, (long)PT * d.Tp, w.xoh + (size_t)nB * d.Tp, bv.p_type, PT, d.Tp);
+    DVAE_TRY(dvae_type_csr(bv.types, nB, bv.p_type, PT, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s));
     if (d.bn) {
         DVAE_TRY(dvae_gru_pointwise_bwd(w.dst, Hp, w.gates, w.ghn, w.agg, Hp, w.dgh, w.dgin, w.dagg, Hp, NST, Hp, s));
         DVAE_TRY(lin_dgrad(w.dgh, 3 * Hp, whh, Hp, w.dagg, Hp, nullptr, NST, 3 * Hp, Hp, 1, s));

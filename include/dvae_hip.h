@@ -192,6 +192,19 @@ int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t co
 int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                             int32_t seg_rows, int32_t width, void* stream);
 
+/* The input-side and bias gradients of a GRUCell whose input is a one-hot vertex type (models.py:653,
+ * :670): with x = onehot(type), d W_ih[:, t] and d b_ih are per-type column sums of the gate gradients.
+ * dvae_type_csr sorts the rows na + nb (two type arrays laid end to end; nb may be 0) by type:
+ * off[T + 1], idx[na + nb].  dvae_type_colsum reads dgh [rows][3Hp] and dgin [rows][Hp] once and ADDS
+ *   gi[t][0:2Hp]   += sum over rows of type t of dgh[:, 0:2Hp]
+ *   bhn[0:Hp]      += sum over all rows of dgh[:, 2Hp:3Hp]
+ *   gi[t][2Hp:3Hp] += sum over rows of type t of dgin
+ * (gi [T][3Hp] as for dvae_gru_pointwise_fwd; fp32 atomics, so the last bits vary run to run). */
+int dvae_type_csr(const int32_t* types_a, int32_t na, const int32_t* types_b, int32_t nb, int32_t T, int32_t* off,
+                  int32_t* idx, void* stream);
+int dvae_type_colsum(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T, float* gi,
+                     float* bhn, int32_t rows, int32_t Hp, void* stream);
+
 /* Edge predictor tail + BCE (models.py:745, :855): per pair p
  *   s = b2 + sum_j w2[j] relu(EA[a_p][j] + EB[h_p][j] (+ EC[c_p][j]) + b1[j])
  *   prob = sigmoid(s);  loss_p = -(t log prob + (1-t) log(1-prob)), logs clamped at -100

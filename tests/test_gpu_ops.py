@@ -715,3 +715,40 @@ def test_gemm_relu_mask_epilogue(M, N, K, bf16):
     # not combinable with accumulate
     d.accumulate = 1
     assert fn(C.byref(d), _s()) != 0
+
+
+@pytest.mark.parametrize("rows,nb,Hp,T", [(8192, 0, 512, 8), (300, 77, 96, 7), (5, 0, 32, 3)])
+def test_type_csr_and_type_colsum_match_torch(rows, nb, Hp, T):
+    """rows sorted by type + one sweep == the per-type column sums (d W_ih, d b_ih of a GRUCell with one-hot
+    input) and the all-rows column sum (d b_hn) computed with torch in fp64."""
+    g = torch.Generator().manual_seed(rows + Hp)
+    n = rows + nb
+    types = torch.randint(0, T, (n,), generator=g).int().cuda()
+    dgh = torch.randn(n, 3 * Hp, generator=g).cuda()
+    dgin = torch.randn(n, Hp, generator=g).cuda()
+    off = torch.full((T + 1,), -1, dtype=torch.int32).cuda()
+    idx = torch.full((n,), -1, dtype=torch.int32).cuda()
+    lib = L.load()
+    tb = types[rows:] if nb else None
+    L.check(lib.dvae_type_csr(types.data_ptr(), rows, tb.data_ptr() if nb else None, nb, T, off.data_ptr(), idx.data_ptr(), _s()))
+    torch.cuda.synchronize()
+    cnt = torch.bincount(types.long(), minlength=T).cpu()
+    assert off.cpu().tolist() == [0] + cnt.cumsum(0).tolist()
+    ic = idx.cpu().long()
+    assert sorted(ic.tolist()) == list(range(n))
+    for t in range(T):
+        assert (types.cpu()[ic[off[t].item():off[t + 1].item()]] == t).all()
+    gi = torch.randn(32, 3 * Hp, generator=g).cuda()
+    bhn = torch.randn(Hp, generator=g).cuda()
+    gi0, bhn0 = gi.clone(), bhn.clone()
+    L.check(lib.dvae_type_colsum(dgh.data_ptr(), dgin.data_ptr(), off.data_ptr(), idx.data_ptr(), T, gi.data_ptr(),
+                                 bhn.data_ptr(), n, Hp, _s()))
+    torch.cuda.synchronize()
+    oh = torch.nn.functional.one_hot(types.long(), 32).double()
+    ref_gi = gi0.double().clone()
+    ref_gi[:, :2 * Hp] += oh.t() @ dgh[:, :2 * Hp].double()
+    ref_gi[:, 2 * Hp:] += oh.t() @ dgin.double()
+    ref_bhn = bhn0.double() + dgh[:, 2 * Hp:].double().sum(0)
+    scale = max(1.0, n ** 0.5)
+    assert (gi.double() - ref_gi).abs().max() < 2e-5 * scale
+    assert (bhn.double() - ref_bhn).abs().max() < 2e-5 * scale
