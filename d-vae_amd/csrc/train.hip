@@ -430,6 +430,16 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     const bool fused = chain_fused_bwd(d, c->B);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
+    // csr_on_side: the type sort is a one-workgroup, latency-bound kernel that depends on the batch only; with
+    // two directions it runs on the (still idle) side stream under the head of this function, and the main
+    // stream picks it up with the join below, long after it has finished
+    Side* side = nullptr;
+    if (dirs == 2) {
+        DVAE_TRY(side_for_current_device(&side));
+        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40,
+                               side->stream));
+    }
     EW(join_mu_logvar_kernel, (long)B * NZ2, w.d12, dmu, dlogvar, B, d.nz, d.NZp);
     const float* hgu = d.bidir ? w.hgu : w.hg;
     const int ld_hgu = d.bidir ? Hp : 2 * Hp;
@@ -445,8 +455,10 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         dhg = w.dhg;
         ld_dhg = 2 * Hp;
     }
-    // rows sorted by vertex type, for the GRUs' input-side gradients (off at xoh[0..T], idx from xoh[40])
-    DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s));
+    // rows sorted by vertex type, for the GRUs' input-side gradients (off at xoh[0..T], idx from xoh[40]): with two
+    // directions it was enqueued on the side stream at the top of this function (csr_on_side below)
+    if (dirs == 1)
+        DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s));
 
     auto begin_dir = [&](int k, hipStream_t s) -> int {
         DVAE_HIP(hipMemsetAsync(w.dhs[k], 0, sizeof(float) * (size_t)nB * Hp, s));
@@ -522,8 +534,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // as in the forward pass: two streams, enqueued level by level in turn
     // (as in the forward pass: optionally both directions of a level as one grid)
     const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
-    Side* side = nullptr;
-    if (dirs == 2) DVAE_TRY(side_for_current_device(&side));
+    if (dirs == 2) DVAE_TRY(join_side(side, s));  // the type sort (csr_on_side)
     if (dirs == 2 && !merged) {
         DVAE_TRY(fork_side(side, s));
         DVAE_TRY(begin_dir(1, side->stream));
@@ -738,6 +749,9 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(fork_side(side, s));
     {
         hipStream_t s2 = side->stream;
+        // rows sorted by vertex type (off at xoh[0..T], idx from xoh[40]) for the GRU's input-side gradients, which
+        // run on this stream at the end: a one-workgroup kernel bound by latency, kept off the main stream
+        DVAE_TRY(dvae_type_csr(bv.types, nB, bv.p_type, PT, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s2));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s2));
         DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
@@ -758,7 +772,6 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(dvae_gather_sum_f32(w.dst, Hp, w.dvs, Hp, bv.vst_off, bv.vst_idx, nB, Hp, 1, s));
 
     // ---- states --------------------------------------------------------------------
-    DVAE_TRY(dvae_type_csr(bv.types, nB, bv.p_type, PT, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s));
     if (d.bn) {
         DVAE_TRY(dvae_gru_pointwise_bwd(w.dst, Hp, w.gates, w.ghn, w.agg, Hp, w.dgh, w.dgin, w.dagg, Hp, NST, Hp, s));
         DVAE_TRY(lin_dgrad(w.dgh, 3 * Hp, whh, Hp, w.dagg, Hp, nullptr, NST, 3 * Hp, Hp, 1, s));
