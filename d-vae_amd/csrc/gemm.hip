@@ -361,6 +361,11 @@ static int launch_cfg(GemmParams p, int akm, int bkm, hipStream_t s) {
     return DVAE_OK;
 }
 
+// Span (bytes from the base pointer) a K-major operand may cover: 32-bit buffer offsets.  Tests lower it
+// through dvae_debug_set_kmajor_span_limit to run the chunked path and the gather guard at small sizes.
+static double g_kmajor_span_limit = 4294967000.0;
+double kmajor_span_limit() { return g_kmajor_span_limit; }
+
 // argument checks common to both kernels; kmult = granularity of K for K-contiguous operands
 int gemm_check(const dvae_gemm_desc& d, int kmult) {
     DVAE_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative size");
@@ -375,6 +380,14 @@ int gemm_check(const dvae_gemm_desc& d, int kmult) {
     DVAE_REQUIRE(d.ldc >= d.N, "gemm: ldc < N");
     DVAE_REQUIRE(d.act >= 0 && d.act <= 2, "gemm: unknown activation %d", d.act);
     DVAE_REQUIRE(!d.relu_mask || !d.accumulate, "gemm: relu_mask cannot be combined with accumulate");
+    if (d.b_kmajor && d.b_rows) {
+        // a row-gathered K-major operand is addressed as (row index * ldb + column) * 4 in 32 bits: the rows the
+        // index list may name must all lie within the addressable span (chunking over K cannot rebase a gather)
+        DVAE_REQUIRE(d.b_rows_bound > 0, "gemm: a row-gathered K-major B needs b_rows_bound (rows of the stored matrix)");
+        DVAE_REQUIRE((double)d.b_rows_bound * d.ldb * 4.0 < kmajor_span_limit(),
+                     "gemm: row-gathered K-major B spans %.0f bytes (b_rows_bound %d x ldb %d floats), limit %.0f",
+                     (double)d.b_rows_bound * d.ldb * 4.0, d.b_rows_bound, d.ldb, kmajor_span_limit());
+    }
     return DVAE_OK;
 }
 
@@ -382,7 +395,7 @@ int gemm_check(const dvae_gemm_desc& d, int kmult) {
 // K-major operand spans more than 4 GiB runs as a sequence of accumulating K chunks.  Returns
 // the chunk length (a multiple of `bk`; >= K when no chunking is needed) or a negative error.
 int gemm_k_chunk(const dvae_gemm_desc& d, int bk) {
-    const double lim = 4294967000.0;
+    const double lim = kmajor_span_limit();
     double rowb = 0.0;
     if (d.a_kmajor) rowb = d.lda * 4.0;
     if (d.b_kmajor && !d.b_rows && d.ldb * 4.0 > rowb) rowb = d.ldb * 4.0;
@@ -511,6 +524,12 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
 }
 
 }  // namespace dvae
+
+extern "C" int dvae_debug_set_kmajor_span_limit(int64_t bytes) {
+    DVAE_REQUIRE(bytes >= 0 && (double)bytes <= 4294967000.0, "span limit must be in 0 .. 4294967000 (0 restores the default)");
+    dvae::g_kmajor_span_limit = bytes == 0 ? 4294967000.0 : (double)bytes;
+    return DVAE_OK;
+}
 
 extern "C" int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream) {
     if (!d) return dvae::set_err(DVAE_ERR_ARG, "dvae_gemm_f32: null descriptor");

@@ -139,6 +139,7 @@ inline bool gemm_vec_epilogue_ok(const GemmParams& p) {
 
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16.hip
 int gemm_check(const dvae_gemm_desc& d, int kmult);     // gemm.hip: argument checks common to both
+double kmajor_span_limit();                              // bytes a K-major operand may span (32-bit offsets)
 int gemm_k_chunk(const dvae_gemm_desc& d, int bk);
 bool gemm_next_chunk(const dvae_gemm_desc& d, int kc, int& k0, dvae_gemm_desc& sub);
 

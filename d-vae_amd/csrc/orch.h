@@ -31,11 +31,12 @@ static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* d
     return run_gemm(g, s);
 }
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
+// xrows (nullable) gathers the rows of X; xrows_bound = rows of the stored X the list may name
 static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
-                     int N, int K, hipStream_t s) {
+                     int N, int K, hipStream_t s, int xrows_bound = 0) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
-    g.M = N; g.N = K; g.K = M; g.accumulate = 1;
+    g.M = N; g.N = K; g.K = M; g.accumulate = 1; g.b_rows_bound = xrows_bound;
     return run_gemm(g, s);
 }
 

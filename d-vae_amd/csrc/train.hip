@@ -756,8 +756,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
-        DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2));
-        DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2));
+        DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2, NST));
+        DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2, NST));
         if (d.bn) DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s2));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s2));
         DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s2));

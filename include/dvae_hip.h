@@ -58,8 +58,17 @@ typedef struct dvae_gemm_desc {
     int32_t accumulate;
     const float* relu_mask; /* nullable, [M][ldc] laid out like C: C = mask > 0 ? result : 0 (the backward of a
                                ReLU whose output is `mask`, models.py:566 add_vertex; not with accumulate) */
+    int32_t b_rows_bound;   /* with b_kmajor and b_rows: the number of rows of the stored B matrix (every index in
+                               b_rows is below it).  Required there: K-major operands are addressed with 32-bit byte
+                               offsets, and a gather cannot be rebased chunk by chunk, so b_rows_bound * ldb * 4 must
+                               stay below 4 GiB or the call is refused.  Ignored otherwise. */
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
+/* Diagnostics: lowers the span (bytes from its base pointer) a K-major operand may cover, normally
+ * 4 GiB - a contraction over a longer K-major operand runs as accumulating K chunks, a longer gathered one is
+ * refused - so that tests reach both paths at small sizes.  0 restores the default.  Process-wide, not
+ * thread-safe; no counterpart in the reference. */
+int dvae_debug_set_kmajor_span_limit(int64_t bytes);
 /* The same product with the operands rounded to bf16 (round to nearest even) on
  * their way into the matrix unit (v_mfma_f32_32x32x16_bf16, fp32 accumulate);
  * operands and result stay fp32 in memory.  K-contiguous operands need only

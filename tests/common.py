@@ -59,6 +59,42 @@ def oracle_truth(cls, ctor, sd, types, adj, n_g, eps):
     return r32, r64
 
 
+def grad_error_table(model, r32, r64):
+    """per parameter tensor: relative error of the HIP gradient and of the fp32 reference arithmetic, both
+    against the fp64 oracle -- the two numbers assert_grads_match compares"""
+    table = {}
+    for k, p in model.named_parameters():
+        g64 = r64[5][k]
+        if g64 is None or p.grad is None:
+            continue
+        table[k] = {"e_hip": rel_err(p.grad, g64), "e_ref": rel_err(r32[5][k], g64), "numel": p.numel()}
+    return table
+
+
+def log_parity(name, payload):
+    """leaves a JSON record under gpurun_out/parity/ (merged back from the GPU box; the summaries that are
+    judged are copied to profiles/)"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "parity")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+    except OSError:
+        pass  # read-only tree: the record is a by-product, never a reason to fail
+
+
+_TRUTH_CACHE = {}
+
+
+def oracle_truth_cached(key, cls, ctor, sd, types, adj, n_g, eps):
+    """oracle_truth, computed once per fixture and process (the fp64 oracle at n = 64, hs = 1024 takes a minute)"""
+    if key not in _TRUTH_CACHE:
+        _TRUTH_CACHE[key] = oracle_truth(cls, ctor, sd, types, adj, n_g, eps)
+    return _TRUTH_CACHE[key]
+
+
 def assert_grads_match(model, r32, r64, tol=1e-4, slack=1.5):
     """Gradient parity.  The decoder's ReLU layers make the gradient discontinuous:
     a pre-activation within fp32 rounding of 0 flips its mask, and ONE flip moves

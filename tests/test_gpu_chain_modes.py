@@ -13,7 +13,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORCED = {"DVAE_CHAIN_FUSED": "2", "DVAE_CHAIN_FUSED_BWD": "2"}
-CASES = "tiny_matches_reference_golden or random_graphs_match_oracle or max_size_graphs_n64 or edge_cases_smallest"
+CASES = ("tiny_matches_reference_golden or random_graphs_match_oracle or max_size_graphs_n64 or edge_cases_smallest "
+         "or (hs501_matches_reference_golden and cfg4)")
 
 
 @pytest.mark.parametrize("extra", [{}, {"DVAE_CHAIN_KS": "2"}, {"DVAE_CHAIN_MERGE": "1"}],

@@ -27,6 +27,7 @@ def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None
     d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), Cm.stride(0)
     d.M, d.N, d.K = M, N, K
     d.a_kmajor, d.b_kmajor, d.act, d.accumulate = akm, bkm, act, acc
+    d.b_rows_bound = B.shape[0] if (b_rows is not None and bkm) else 0
     fn = L.load().dvae_gemm_bf16 if bf16 else L.load().dvae_gemm_f32
     L.check(fn(C.byref(d), _s()), "gemm")
     torch.cuda.synchronize()
@@ -96,6 +97,80 @@ def test_gemm_wgrad_splitk(rows, N, K):
     _gemm(dY, X, out, N, K, rows, akm=1, bkm=1, b_rows=b_rows, acc=1)
     ref = _ref(dY.t(), X[b_rows.long()])
     assert (out - ref).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
+
+
+@pytest.fixture
+def span_limit():
+    """lowers the span a K-major operand may cover (normally 4 GiB) for one test"""
+    lib = L.load()
+
+    def set_limit(nbytes):
+        L.check(lib.dvae_debug_set_kmajor_span_limit(int(nbytes)), "span limit")
+    yield set_limit
+    lib.dvae_debug_set_kmajor_span_limit(0)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("form", ["wgrad", "dgrad"])
+def test_gemm_kmajor_operand_beyond_the_span_limit_runs_in_k_chunks(form, bf16, span_limit):
+    """A contraction whose K-major operand spans more than 4 GiB (cfg 5: the 3072 x 1024 x 479 k weight
+    gradient) runs as accumulating K chunks (gemm_k_chunk / gemm_next_chunk).  With the span limit lowered
+    to 1 MB the same path runs at a test size: ragged last chunk, chunk offsets on both operands, a
+    pre-loaded accumulator, and the same numbers as the unchunked product."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    if form == "wgrad":  # dW[N, K] += dY[rows, N]^T X[rows, K]: both operands K-major, K = rows
+        rows, N, K = 2500, 160, 192
+        A = torch.randn(rows, N, device="cuda", generator=g)
+        Bm = torch.randn(rows, K, device="cuda", generator=g)
+        args = dict(M=N, N=K, K=rows, akm=1, bkm=1, acc=1)
+        ref = 0.25 + (A.double().t() @ Bm.double()).float()
+        shape = (N, K)
+    else:                # dX[M, K] = dY[M, N] W[N, K]: B K-major, contraction over N
+        M, N, K = 300, 2208, 160
+        A = torch.randn(M, N, device="cuda", generator=g)
+        Bm = torch.randn(N, K, device="cuda", generator=g)
+        args = dict(M=M, N=K, K=N, akm=0, bkm=1, acc=1)
+        ref = 0.25 + (A.double() @ Bm.double()).float()
+        shape = (M, K)
+    if bf16:
+        ra, rb = A.bfloat16().double(), Bm.bfloat16().double()
+        ref = 0.25 + ((ra.t() @ rb) if form == "wgrad" else (ra @ rb)).float()
+    whole = torch.full(shape, 0.25, device="cuda")
+    _gemm(A, Bm, whole, bf16=bf16, **args)
+    span_limit(1 << 20)  # 1 MB: rows of 640 / 768 bytes -> chunks of about 1300 - 1600 k, so 2 chunks
+    chunked = torch.full(shape, 0.25, device="cuda")
+    _gemm(A, Bm, chunked, bf16=bf16, **args)
+    tol = 2e-3 if not bf16 else 2e-2
+    assert (whole - ref).abs().max() < tol and (chunked - ref).abs().max() < tol
+    # (split-K sums arrive in any order: the two runs agree to rounding, not bit for bit)
+    assert (chunked - whole).abs().max() < 1e-3
+    span_limit(1 << 12)  # a limit below one K step of rows is refused, not mis-addressed
+    with pytest.raises(L.DvaeHipError, match="leading dimension too large"):
+        _gemm(A, Bm, chunked, bf16=bf16, **args)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_gemm_row_gathered_kmajor_operand_is_bounded(bf16, span_limit):
+    """A row-gathered K-major operand (the edge predictor's weight gradients gather state rows) is addressed
+    with 32-bit offsets and cannot be chunked: the caller states how many rows the stored matrix has and a
+    matrix beyond the span limit is refused instead of wrapping."""
+    g = torch.Generator(device="cuda").manual_seed(78)
+    rows, N, K = 600, 64, 96
+    dY = torch.randn(rows, N, device="cuda", generator=g)
+    X = torch.randn(rows + 40, K, device="cuda", generator=g)
+    b_rows = torch.randperm(rows + 40, device="cuda", generator=g)[:rows].int()
+    out = torch.zeros(N, K, device="cuda")
+    _gemm(dY, X, out, N, K, rows, akm=1, bkm=1, b_rows=b_rows, acc=1, bf16=bf16)
+    span_limit(X.numel() * 4 - 4)  # one float short of the stored matrix
+    with pytest.raises(L.DvaeHipError, match="row-gathered K-major B spans"):
+        _gemm(dY, X, out, N, K, rows, akm=1, bkm=1, b_rows=b_rows, acc=1, bf16=bf16)
+    span_limit(0)
+    d = L.GemmDesc()  # the bound is required
+    d.A, d.B, d.C, d.b_rows = dY.data_ptr(), X.data_ptr(), out.data_ptr(), b_rows.data_ptr()
+    d.lda, d.ldb, d.ldc, d.M, d.N, d.K = N, K, K, N, K, rows
+    d.a_kmajor = d.b_kmajor = d.accumulate = 1
+    assert L.load().dvae_gemm_f32(C.byref(d), _s()) != 0
+    assert b"b_rows_bound" in L.load().dvae_last_error()
 
 
 @pytest.mark.parametrize("case", ["n_not_mult4", "ldc_not_mult4", "bias_unaligned", "c_unaligned"])

@@ -11,7 +11,7 @@ import torch
 
 from _dvae_pkg import dvae_amd
 from common import (golden_files, load_case, cfg_of, make_model, state_dict_of, rel_err, oracle_truth,
-                    assert_grads_match)
+                    oracle_truth_cached, assert_grads_match, grad_error_table, log_parity)
 import dvae_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,6 +50,25 @@ def test_tiny_matches_reference_golden(path):
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert rel_err(p.grad, torch.from_numpy(d["grad::" + k])) < TOL, k
+    _check_adam_delta(model, ga, torch.from_numpy(d["eps"]), float(d["adam_delta_abs_sum"]), 2e-4)
+
+
+def _check_adam_delta(model, ga, eps, golden, tol):
+    """One optimizer step of the reference (torch.optim.Adam, lr 1e-4, train.py:174) moved the parameters by
+    `golden` = sum |delta| over all of them (oracle/gen_golden.py): the same step through the HIP
+    path -- backward into the flat gradient buffer, FlatAdam's one launch -- must move them as far."""
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-4)
+    opt.zero_grad()
+    batch = model._collate_fn(ga)
+    mu, logvar = model.encode(batch)
+    loss, _, _ = model.loss(mu, logvar, batch, eps=eps)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    moved = sum((p.detach().double() - before[k].double()).abs().sum().item() for k, p in model.named_parameters())
+    assert abs(moved - golden) <= tol * golden, (moved, golden)
+    return moved
 
 
 @pytest.mark.parametrize("path", BIG, ids=[os.path.basename(p)[:-4] for p in BIG])
@@ -70,7 +89,7 @@ def test_hs501_matches_reference_golden(path):
         gn = d["gnorm::" + k]
         assert abs(p.grad.double().norm().item() - gn[0]) <= 1e-3 * gn[0] + 1e-9, k
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    r32, r64 = oracle_truth(cls, ctor, sd, d["types"], d["adj"], d["n_g"], torch.from_numpy(d["eps"]))
+    r32, r64 = oracle_truth_cached(path, cls, ctor, sd, d["types"], d["adj"], d["n_g"], torch.from_numpy(d["eps"]))
     # the golden slices (reference run in the build container) agree with the exact gradient to
     # within the reference's own fp32 noise, and so do the HIP gradients ...
     for k, p in model.named_parameters():
@@ -79,7 +98,40 @@ def test_hs501_matches_reference_golden(path):
             scale = max(gn_typ(d, k, p), sl.abs().max().item())
             assert (p.grad.reshape(-1)[:sl.numel()].cpu() - sl).abs().max() <= 5e-3 * scale + 1e-7, k
     # ... and, tensor by tensor, the HIP gradients are as close to the exact ones as the reference's are
+    table = grad_error_table(model, r32, r64)
+    log_parity("grad_errors_" + os.path.basename(path)[:-4], {
+        "case": os.path.basename(path), "what": "relative error per gradient tensor against the fp64 oracle: e_hip = this "
+        "library (fp32 MFMA), e_ref = the reference's fp32 arithmetic (oracle in fp32); bar: e_hip <= 1e-4 + 1.5 e_ref",
+        "loss_rel": abs(loss.item() - ref[0]) / abs(ref[0]), "mu_rel": rel_err(mu, torch.from_numpy(d["mu"])),
+        "worst_e_hip": max(v["e_hip"] for v in table.values()), "worst_e_ref": max(v["e_ref"] for v in table.values()),
+        "tensors": table})
     assert_grads_match(model, r32, r64, TOL)
+    moved = _check_adam_delta(model, ga, torch.from_numpy(d["eps"]), float(d["adam_delta_abs_sum"]), 1e-3)
+    print("%s: adam delta %.6f (reference %.6f)" % (os.path.basename(path), moved, float(d["adam_delta_abs_sum"])))
+
+
+def test_cfg5_shape_bf16_mode_close_to_oracle():
+    """BASELINE cfg 5 names bf16 MFMA inputs at n = 64, nvt = 18, hs = 1024: the reference-golden batch of that
+    shape in the reduced-precision mode, against the fp64 oracle, at the stated bf16 tolerances."""
+    path = golden_files("dvae_cfg5_bi")[0]
+    d, cls, ctor = load_case(path)
+    model = make_model(cls, ctor, int(d["seed"]))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    eps = torch.from_numpy(d["eps"])
+    r32, r64 = oracle_truth_cached(path, cls, ctor, sd, d["types"], d["adj"], d["n_g"], eps)
+    model.set_mfma_dtype("bf16").cuda()
+    loss, res, kld, mu, logvar = _run(model, dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"]), eps)
+    e_loss = abs(loss.item() - r64[0].item()) / abs(r64[0].item())
+    table = {k: rel_err(p.grad, r64[5][k]) for k, p in model.named_parameters() if p.grad is not None}
+    log_parity("bf16_errors_dvae_cfg5_bi", {"loss_rel": e_loss, "mu_rel": rel_err(mu, r64[3]),
+                                            "logvar_rel": rel_err(logvar, r64[4]), "grad_rel": table,
+                                            "tolerances": {"loss": BF16_TOL_LOSS, "latent": BF16_TOL_LATENT,
+                                                           "grad": BF16_TOL_GRAD}})
+    assert e_loss <= BF16_TOL_LOSS
+    assert rel_err(mu, r64[3]) < BF16_TOL_LATENT and rel_err(logvar, r64[4]) < BF16_TOL_LATENT
+    for k, e in table.items():
+        assert e < BF16_TOL_GRAD, "%s: %.3e" % (k, e)
+    assert rel_err(mu, r64[3]) > 1e-5  # the flag is not silently ignored
 
 
 def gn_typ(d, k, p):
@@ -167,6 +219,38 @@ def test_full_batch_properties_cfg2():
     # oracle on a slice
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     sl = slice(100, 116)
+    r32, r64 = oracle_truth("DVAE", ctor, sd, types[sl], adj[sl], n_g[sl], eps[sl])
+    l3, _, _, mu3, _ = _run(model, ga[sl], eps[sl])
+    assert abs(l3.item() - r64[0].item()) <= TOL * abs(r64[0].item())
+    assert rel_err(mu3, r64[3]) < TOL
+    assert_grads_match(model, r32, r64, TOL)
+
+
+def test_full_batch_properties_cfg4():
+    """BASELINE config 4 size (ENAS-12: n = 14, nvt = 8, hs = 501, bidirectional, 1024 graphs per GPU), where the
+    fused level kernels run by default: two half-batches (which run the GEMM + pointwise launches) add up to the
+    full batch in the loss and in every gradient, and a 16-graph slice matches the oracle."""
+    rng = np.random.default_rng(4)
+    n, T, B = 14, 8, 1024
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=501, nz=56, bidirectional=1)
+    model = make_model("DVAE", ctor, 1).cuda()
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.3)
+    eps = torch.from_numpy(rng.standard_normal((B, 56)).astype(np.float32))
+    ga = dvae_amd.GraphArrays.from_dense(types, adj, n_g)
+    loss, res, kld, mu, logvar = _run(model, ga, eps)
+    g_full = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    tot, g_sum = 0.0, None
+    for lo, hi in ((0, 512), (512, 1024)):
+        l2, _, _, mu2, _ = _run(model, ga[lo:hi], eps[lo:hi])
+        tot += l2.item()
+        assert rel_err(mu2, mu[lo:hi]) < 1e-5
+        cur = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        g_sum = cur if g_sum is None else {k: g_sum[k] + cur[k] for k in cur}
+    assert abs(tot - loss.item()) <= 2e-5 * abs(loss.item())
+    for k in g_full:
+        assert rel_err(g_sum[k], g_full[k]) < TOL, k
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sl = slice(200, 216)
     r32, r64 = oracle_truth("DVAE", ctor, sd, types[sl], adj[sl], n_g[sl], eps[sl])
     l3, _, _, mu3, _ = _run(model, ga[sl], eps[sl])
     assert abs(l3.item() - r64[0].item()) <= TOL * abs(r64[0].item())

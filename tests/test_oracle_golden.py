@@ -14,7 +14,7 @@ BIG = golden_files("*cfg*")
 
 
 def test_fixtures_present():
-    assert len(TINY) == 9 and len(BIG) == 3
+    assert len(TINY) == 9 and len(BIG) == 5
 
 
 @pytest.mark.parametrize("path", TINY, ids=[os.path.basename(p)[:-4] for p in TINY])
@@ -36,6 +36,17 @@ def test_oracle_matches_reference_tiny(path, mode):
     for k, g in grads.items():
         if g is not None:
             assert rel_err(g, torch.from_numpy(d["grad::" + k])) < 5e-6, k
+    assert abs(_adam_delta(sd, grads) - float(d["adam_delta_abs_sum"])) <= 1e-4 * float(d["adam_delta_abs_sum"])
+
+
+def _adam_delta(sd, grads):
+    """sum |delta parameter| of ONE torch.optim.Adam step (lr 1e-4, train.py:174) on the oracle's gradients: the
+    checksum oracle/gen_golden.py stored after the reference's own optimizer step"""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    for k, p in params.items():
+        p.grad = None if grads.get(k) is None else grads[k].detach().clone().to(p.dtype)
+    torch.optim.Adam(list(params.values()), lr=1e-4).step()
+    return sum((p.detach().double() - sd[k].double()).abs().sum().item() for k, p in params.items())
 
 
 @pytest.mark.parametrize("path", BIG, ids=[os.path.basename(p)[:-4] for p in BIG])
@@ -64,6 +75,7 @@ def test_oracle_matches_reference_hs501(path):
         assert abs(g.double().norm().item() - gn[0]) <= 2e-5 * gn[0] + 1e-9, k
         sl = torch.from_numpy(d["gslice::" + k])
         assert (g.reshape(-1)[:sl.numel()] - sl).abs().max() <= 2e-5 * max(1e-3, sl.abs().max().item()) + 1e-7, k
+    assert abs(_adam_delta(sd, grads) - float(d["adam_delta_abs_sum"])) <= 1e-3 * float(d["adam_delta_abs_sum"])
 
 
 DECODE = golden_files("decode_*")

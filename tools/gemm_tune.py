@@ -62,7 +62,7 @@ def child_time(shapes_file):
         if int(kv["ar"]) and not akm:
             r = torch.randperm(M, device="cuda", generator=gen).int(); keep.append(r); d.a_rows = r.data_ptr()
         if int(kv["br"]) and bkm:
-            r = torch.randperm(K, device="cuda", generator=gen).int(); keep.append(r); d.b_rows = r.data_ptr()
+            r = torch.randperm(K, device="cuda", generator=gen).int(); keep.append(r); d.b_rows = r.data_ptr(); d.b_rows_bound = K
         if int(kv["cr"]):
             r = torch.randperm(M, device="cuda", generator=gen).int(); keep.append(r); d.c_rows = r.data_ptr()
         st = torch.cuda.current_stream()
