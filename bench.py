@@ -21,29 +21,129 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------------------------
+# Self-launch.  `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset)
+# starts the N ranks itself: one child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+# MASTER_ADDR / MASTER_PORT set, exactly what torch.distributed.run would set.  The parent never
+# touches the GPU (it runs before torch is imported), relays rank 0's ONE JSON line and exits with
+# the first failing rank's code.  Under torch.distributed.run (WORLD_SIZE set) nothing of this runs.
+# ----------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-unit input type: f32 = the parity mode (headline); bf16 = reduced precision, "
+                         "reported separately")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's per-GPU batch on every rank; strong: a fixed global batch "
+                         "(--global-batch, default 8 x the per-GPU batch: cfg 4 = 8192) ceil-split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
+
+
+def launch_plan(argv, environ, port=None):
+    """[] when this process is itself a rank (single GPU, or a launcher set WORLD_SIZE); otherwise one
+    (command, environment) per rank to start."""
+    args = parse_args(argv)
+    if args.gpus <= 1 or "WORLD_SIZE" in environ:
+        return []
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    plan = []
+    for r in range(args.gpus):
+        env = dict(environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        plan.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def self_launch(plan):
+    procs = []
+    for r, (cmd, env) in enumerate(plan):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rc, pending = 0, list(range(len(procs)))
+    while pending:
+        time.sleep(0.05)
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.remove(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # one rank failed: the others would wait in a collective for ever
+                    procs[q].terminate()
+    out0 = procs[0].stdout.read()  # rank 0 prints one line: far below the pipe's capacity, so it never blocked
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if rc == 0 and lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+    return rc
+
+
+if __name__ == "__main__":
+    _plan = launch_plan(sys.argv[1:], os.environ)
+    if _plan:
+        sys.exit(self_launch(_plan))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, ROOT)
 from _dvae_pkg import dvae_amd  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3    # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
-# Memory-side traffic of one launch of the dominant GEMM on its cfg-2 shape (9251 x 2048 x 512),
-# from rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE 58717 KB, doubled per the gfx950
-# correction of MI355X_MICROARCH.md (section HBM), + WRITE_SIZE 74037 KB (profiles/r01_gemm_pmc.json).  Infinity-Cache hits are
-# counted by these counters, so this is traffic behind L2, an upper bound on HBM bytes.
-MEASURED_TRAFFIC = {(9251, 2048, 512): (2 * 58717 + 74037) * 1024}
+PROFILES = os.path.join(ROOT, "profiles")
+
+
+def newest_profile(suffix):
+    """newest round's profiles/rNN_<suffix>, or None"""
+    try:
+        names = sorted(f for f in os.listdir(PROFILES) if f.endswith("_" + suffix) and f[0] == "r" and f[1:3].isdigit())
+    except OSError:
+        return None
+    return os.path.join(PROFILES, names[-1]) if names else None
+
+
+def measured_traffic(shape):
+    """Memory-side bytes of ONE launch of the dominant GEMM, from the committed rocprofv3 PMC passes on that
+    launch (tools/profile_round.sh -> profiles/rNN_gemm_pmc.json): FETCH_SIZE (KB) doubled per the gfx950
+    correction of MI355X_MICROARCH.md (section HBM) + WRITE_SIZE (KB).  Infinity-Cache hits are counted by
+    these counters: traffic behind L2, an upper bound on HBM bytes.  None if the passes were taken on
+    another shape (or are absent)."""
+    path = newest_profile("gemm_pmc.json")
+    if path is None:
+        return None, None
+    pm = json.load(open(path))
+    if list(pm.get("shape_MNK", [9251, 2048, 512])) != list(shape) or "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:
+        return None, os.path.relpath(path, ROOT)
+    return (2.0 * pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(path, ROOT)
 
 CONFIGS = {
     # name: (class, ctor kwargs, per-GPU batch, generator)
     "cfg1": dict(cls="DVAE", max_n=8, nvt=8, hs=501, nz=56, bidir=False, B=32, kind="enas", layers=6, ntypes=6),
     "cfg2": dict(cls="DVAE", max_n=8, nvt=8, hs=501, nz=56, bidir=True, B=1024, kind="enas", layers=6, ntypes=6),
     "cfg3": dict(cls="DVAE_BN", max_n=10, nvt=10, hs=501, nz=56, bidir=False, B=4096, kind="bn", layers=8, ntypes=8),
+    # (strong scaling, SURVEY 8d/e: fixed global batch 8192 = 8 x 1024)
     "cfg4": dict(cls="DVAE", max_n=14, nvt=8, hs=501, nz=56, bidir=True, B=1024, kind="enas", layers=12, ntypes=6),
     # 64-vertex synthetic DAGs: layer i takes an optional edge from j < i with probability min(0.30, 3 / i)
     "cfg5": dict(cls="DVAE", max_n=64, nvt=18, hs=1024, nz=56, bidir=True, B=2048, kind="enas", layers=62, ntypes=16,
@@ -84,6 +184,45 @@ def f_alg_macs(cfg, ga):
     vert = (n - 1) * (2 * H * H + 2 * H * T)
     head = 3 * H * nz + (2 * H * H if cfg["bidir"] else 0)
     return gru + gm + vert + edge + head, float(E), float(od0)
+
+
+def executed_mfma_macs(cfg, c):
+    """Forward MACs the step actually ISSUES on the matrix units for one batch, from the packed batch's
+    counts `c`: feature dimensions padded (hs 501 -> 512, nz 56 -> 64, nvt -> 32), states without predecessors
+    de-duplicated to one row per type (PT, NB), the first encoder level (h_prev = 0) skipped.  Every product
+    has its two gradient products in the backward pass, so the train step issues 3 x this (x 2 FLOP/MAC).
+    Row padding to whole 64 / 128-row tiles is not counted (< 1 %)."""
+    n, B = cfg["max_n"], int(c.B)
+    Hp = (cfg["hs"] + 31) // 32 * 32
+    NZp = (cfg["nz"] + 31) // 32 * 32
+    Tp, HVp = 32, 2 * Hp
+    bn = cfg["cls"] == "DVAE_BN"
+    HEp = Hp if bn else 4 * Hp
+    dirs = 2 if cfg["bidir"] else 1
+    nB, PT, NA, NB, R = int(c.nB), int(c.PT), int(c.NA), int(c.NB), int(c.R)
+    if bn:
+        enc = dirs * nB * 3 * Hp * Hp                          # no recurrence: one batched hidden product per direction
+        dec = (nB + PT) * 3 * Hp * Hp + B * HEp * Hp           # + the H0 block of the edge predictor
+    else:
+        enc = dirs * (n - 1) * B * 5 * Hp * Hp                 # GRU (3Hp) + gate|mapper (2Hp) per level
+        dec = n * B * 3 * Hp * Hp + (n - 1) * B * 2 * Hp * Hp + PT * 3 * Hp * Hp
+    head = B * 2 * NZp * Hp + B * Hp * NZp + (B * 2 * Hp * Hp if cfg["bidir"] else 0)
+    edge = (NA + NB) * HEp * Hp
+    vert = R * HVp * Hp + R * Tp * HVp
+    return float(enc + dec + head + edge + vert)
+
+
+def roofline_by_kernel():
+    """Per-kernel-family share of the step and fraction of the MFMA peak, from the newest committed rocprofv3
+    kernel-trace summary of this workload (tools/roofline_by_kernel.py writes profiles/rNN_roofline_by_kernel.json
+    from profiles/rNN_bench_cfg2_kernel_stats.csv).  A profile of an earlier run of the same command, not a
+    measurement of this run: `source` names the file."""
+    path = newest_profile("roofline_by_kernel.json")
+    if path is None:
+        return None
+    d = json.load(open(path))
+    d["source"] = os.path.relpath(path, ROOT)
+    return d
 
 
 def time_dominant_gemm(cfg, batch, iters=30, bf16=False):
@@ -160,25 +299,14 @@ def cpu_baseline(cfg, budget_s=20.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="matrix-unit input type: f32 = the parity mode (headline); bf16 = reduced precision, "
-                         "reported separately")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
     cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
@@ -204,26 +332,52 @@ def main():
     reducer = dvae_amd.dist.GradSumReducer(model)
     opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
 
-    # pre-packed batches: weak scaling, every rank owns B graphs per step
+    # pre-packed batches.  weak: every rank owns B graphs per step (its own synthetic draw);
+    # strong: every rank owns its contiguous ceil-split chunk (util.py:566-572) of the same global batch.
+    # Either way eps is the rank's row range of ONE global normal draw (N-rank parity rule).
     B = int(os.environ.get("DVAE_BENCH_B", cfg["B"]))  # diagnostic override (batch-size sweeps); not a bench line
     n_batches = cfg.get("n_batches", 4)
-    graphs = [make_graphs(cfg, B, seed=1000 * rank + i) for i in range(n_batches)]  # synthetic data: not timed
+    strong = args.scaling == "strong"
+    if strong:
+        Bg = args.global_batch or 8 * B
+        lo, hi = dvae_amd.batching.shard_bounds(Bg, world, rank)
+        graphs = [make_graphs(cfg, Bg, seed=5000 + i)[lo:hi] for i in range(n_batches)]  # synthetic data: not timed
+    else:
+        Bg = world * B
+        lo, hi = rank * B, (rank + 1) * B
+        graphs = [make_graphs(cfg, B, seed=1000 * rank + i) for i in range(n_batches)]
+    B_rank = hi - lo
+    if B_rank <= 0:
+        raise SystemExit("rank %d has no graphs (global batch %d over %d ranks)" % (rank, Bg, world))
     model._collate_fn(graphs[0])  # first call: library load, allocator warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     batches = [model._collate_fn(ga) for ga in graphs]  # host packer (C++) + the index blob's copy to the GPU
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t0) * 1e3 / n_batches
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    eps = [torch.randn(B, cfg["nz"], device=dev, generator=gen) for _ in range(n_batches)]
+    eps = []
+    for i in range(n_batches):
+        gen = torch.Generator().manual_seed(7 + i)
+        eps.append(torch.randn(Bg, cfg["nz"], generator=gen)[lo:hi].contiguous().to(dev))
 
-    def step(i):
+    stream = torch.cuda.current_stream()
+    exchange = world > 1 or os.environ.get("DVAE_FORCE_COLLECTIVE") == "1"
+    ar_events = []
+
+    def step(i, timed=False):
         b = batches[i % n_batches]
         reducer.zero()
         mu, logvar = model.encode(b)
         loss, _, _ = model.loss(mu, logvar, b, eps=eps[i % n_batches])
         loss.backward()
-        reducer.all_reduce()
+        if exchange and timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            reducer.all_reduce()
+            e1.record(stream)
+            ar_events.append((e0, e1))
+        else:
+            reducer.all_reduce()
         opt.step()
         return loss
 
@@ -237,7 +391,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = step(i)
+        last = step(i, True)
     host_dt = time.perf_counter() - t0  # host time to ENQUEUE the steps (the GPU runs behind it)
     barrier()
     dt = time.perf_counter() - t0
@@ -245,37 +399,55 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss_val = float(last.item())
+    # the exchange step as the compute stream sees it (the part not hidden behind the encoder's backward)
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events) if ar_events else 0.0
+    loss_global = float(reducer.reduce_scalars(last)[0].item())  # sum over the ranks' shards of the last global batch
 
     if rank == 0:
         macs, E, od0 = f_alg_macs(cfg, batches[0].arrays)
         train_flop_per_dag = 6.0 * macs
-        dags_per_s = world * B * args.steps / dt
+        dags_per_s = Bg * args.steps / dt
+        exec_flop_per_step = 6.0 * executed_mfma_macs(cfg, batches[0].counts)
         roof = time_dominant_gemm(cfg, batches[0], bf16=bf16)
+        traffic, traffic_src = (None, None) if bf16 else measured_traffic(roof["shape"])
         out = {
             "metric": "DAGs/sec train step (ENAS6, hs=501)" if args.config in ("cfg1", "cfg2") else
                       "DAGs/sec train step (%s)" % args.config,
             "value": dags_per_s, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s: %s%s hs=%d nz=%d on synthetic %s DAGs (n=%d, nvt=%d), %d DAGs per GPU per step, "
+            "config": {"workload": "%s: %s%s hs=%d nz=%d on synthetic %s DAGs (n=%d, nvt=%d), %s, "
                                    "full train step incl. Adam%s%s" % (
                                        args.config, cfg["cls"], " bidirectional" if cfg["bidir"] else "", cfg["hs"],
                                        cfg["nz"], "ENAS-%d" % cfg["layers"] if cfg["kind"] == "enas" else "asia-shape BN",
-                                       cfg["max_n"], cfg["nvt"], B, " + RCCL grad all-reduce" if world > 1 else "",
+                                       cfg["max_n"], cfg["nvt"],
+                                       ("global batch %d split over the GPUs" % Bg) if strong else
+                                       ("%d DAGs per GPU per step" % B),
+                                       " + RCCL grad all-reduce" if world > 1 else "",
                                        "; bf16 MFMA inputs, fp32 accumulate / weights / activations" if bf16 else ""),
-                       "global_batch": world * B, "edges_per_dag": E, "outdeg_v0": od0,
+                       "global_batch": Bg, "dags_per_gpu": B_rank, "edges_per_dag": E, "outdeg_v0": od0,
                        "train_gflop_per_dag": train_flop_per_dag / 1e9, "grad_allreduce_mb": reducer.nbytes() / 1e6,
+                       "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0,
+                       "collective_backend": backend if world > 1 else "none",
+                       "allreduce_ms_per_step": ar_ms,
                        "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-                       "loss_last_step": loss_val},
+                       "loss_last_step": loss_global},
             "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": roof["achieved"] / peak,
-                         "traffic": None if bf16 else MEASURED_TRAFFIC.get(tuple(roof["shape"])), "kernel": roof["kernel"],
-                         "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"]},
+                         "frac": roof["achieved"] / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": roof["kernel"], "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"]},
+            # algorithmic rate (the SURVEY 8d contract figure: every DISTINCT module evaluation at dense cost, 6 F_alg
+            # per DAG) and, beside it, the FLOPs the matrix units really execute per step (padded, de-duplicated):
+            # `executed` is the step's MFMA occupancy, `achieved` credits work the restatement avoids
             "step_roofline": {"achieved": train_flop_per_dag * dags_per_s / world / 1e12, "peak": peak,
                               "unit": "TFLOP/s per GPU",
-                              "frac": train_flop_per_dag * dags_per_s / world / 1e12 / peak},
+                              "frac": train_flop_per_dag * dags_per_s / world / 1e12 / peak,
+                              "executed": {"gflop_per_step_per_gpu": exec_flop_per_step / 1e9,
+                                           "achieved": exec_flop_per_step / (dt / args.steps) / 1e12,
+                                           "frac": exec_flop_per_step / (dt / args.steps) / 1e12 / peak}},
         }
+        by_kernel = roofline_by_kernel() if (args.config == "cfg2" and not bf16) else None
+        if by_kernel is not None:
+            out["roofline_by_kernel"] = by_kernel
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

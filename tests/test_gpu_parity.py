@@ -96,7 +96,7 @@ def test_hs501_matches_reference_golden(path):
         if p.grad is not None:
             sl = torch.from_numpy(d["gslice::" + k])
             scale = max(gn_typ(d, k, p), sl.abs().max().item())
-            assert (p.grad.reshape(-1)[:sl.numel()].cpu() - sl).abs().max() <= 5e-3 * scale + 1e-7, k
+            assert (p.grad.reshape(-1)[:sl.numel()].cpu() - sl).abs().max() <= 5e-4 * scale + 1e-7, k
     # ... and, tensor by tensor, the HIP gradients are as close to the exact ones as the reference's are
     table = grad_error_table(model, r32, r64)
     log_parity("grad_errors_" + os.path.basename(path)[:-4], {
@@ -105,7 +105,9 @@ def test_hs501_matches_reference_golden(path):
         "loss_rel": abs(loss.item() - ref[0]) / abs(ref[0]), "mu_rel": rel_err(mu, torch.from_numpy(d["mu"])),
         "worst_e_hip": max(v["e_hip"] for v in table.values()), "worst_e_ref": max(v["e_ref"] for v in table.values()),
         "tensors": table})
-    assert_grads_match(model, r32, r64, TOL)
+    # observed on these fixtures (profiles/r02_parity_hs501_per_tensor.json): every tensor <= 5e-7 at hs = 501 and
+    # <= 5e-5 at hs = 1024, so the bar here is north_star's plain 1e-4 with no allowance for ReLU flips
+    assert_grads_match(model, r32, r64, TOL, slack=0.0)
     moved = _check_adam_delta(model, ga, torch.from_numpy(d["eps"]), float(d["adam_delta_abs_sum"]), 1e-3)
     print("%s: adam delta %.6f (reference %.6f)" % (os.path.basename(path), moved, float(d["adam_delta_abs_sum"])))
 

@@ -185,3 +185,35 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(out["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_bench_self_launch_plumbing(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (the parent never touches the
+    GPU) and relays rank 0's one JSON line; under a launcher (WORLD_SIZE set) or with one GPU it does not."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert bench.launch_plan(["--gpus", "1"], {}) == []
+    assert bench.launch_plan(["--gpus", "4"], {"WORLD_SIZE": "4", "RANK": "2"}) == []
+    plan = bench.launch_plan(["--gpus", "3", "--steps", "7", "--scaling", "strong"], {"KEEP": "1"}, port=23456)
+    assert len(plan) == 3
+    for r, (cmd, env) in enumerate(plan):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "3", "--steps", "7", "--scaling", "strong"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"]) == (str(r), str(r), "3")
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "23456" and env["KEEP"] == "1"
+    # the relay: rank 0's JSON line comes out once; a failing rank ends the job with its code
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "if os.environ.get('FAIL') == str(r): sys.exit(7)\n"
+                      "if os.environ.get('FAIL'): time.sleep(30)\n"
+                      "print('noise'); print('{\"rank\": %d}' % r)\n")
+    import subprocess
+    drv = ("import sys; sys.path.insert(0, %r); import bench, os\n"
+           "plan = [([sys.executable, %r], dict(os.environ, RANK=str(r))) for r in range(3)]\n"
+           "sys.exit(bench.self_launch(plan))\n" % (root, str(script)))
+    ok = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and ok.stdout.strip() == '{"rank": 0}'
+    bad = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=60, env=dict(os.environ, FAIL="1"))
+    assert bad.returncode == 7 and "{" not in bad.stdout
