@@ -89,6 +89,8 @@ SIGNATURES = {
     "dvae_batch_destroy": (None, [_P]),
     "dvae_decode_ws_floats": (C.c_int64, [_MD, _I]),
     "dvae_decode": (_I, [_MD, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "dvae_decode_static_max_floats": (C.c_int64, []),
+    "dvae_decode_static": (_I, [_MD, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dvae_encode_ws_floats": (C.c_int64, [_MD, _BC]),
     "dvae_loss_ws_floats": (C.c_int64, [_MD, _BC]),
     "dvae_encode_forward": (_I, [_MD, _BC, _P, _P, _P, _P, _P, _P]),

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "model.h"
 #include "orch.h"
+#include <mutex>
 
 namespace dvae {
 
@@ -211,9 +212,9 @@ extern "C" int64_t dvae_decode_ws_floats(const dvae_model_desc* m, int32_t B) {
     return (int64_t)carve_gen(d, B, nullptr).total;
 }
 
-extern "C" int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw, float* ws, const float* z,
-                           int32_t stochastic, const float* u_type, const float* u_edge, int32_t* types,
-                           uint64_t* pred_mask, int32_t* n_vertices, void* stream) {
+static int decode_impl(const dvae_model_desc* m, int32_t B, const float* pw, float* ws, const float* z,
+                       int32_t stochastic, const float* u_type, const float* u_edge, int32_t* types,
+                       uint64_t* pred_mask, int32_t* n_vertices, void* stream) {
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_REQUIRE(B > 0, "dvae_decode: empty batch");
@@ -298,4 +299,55 @@ extern "C" int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw,
         if (!forced) DVAE_TRY(finish_vertex(idx));
     }
     return DVAE_OK;
+}
+
+extern "C" int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw, float* ws, const float* z,
+                           int32_t stochastic, const float* u_type, const float* u_edge, int32_t* types,
+                           uint64_t* pred_mask, int32_t* n_vertices, void* stream) {
+    return decode_impl(m, B, pw, ws, z, stochastic, u_type, u_edge, types, pred_mask, n_vertices, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dvae_decode_static: the same generation with the workspace taken from a fixed device array that
+// lives in the library's code object, for callers that cannot allocate (see include/dvae_hip.h).
+// `scratch` is a host-side stand-in for the symbol: its device address is looked up once per device
+// with hipGetSymbolAddress (every GPU holds its own copy at its own address) and only that address
+// is ever handed to kernels or memsets.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[DVAE_DECODE_STATIC_FLOATS];
+
+static int static_scratch_for_current_device(float** out) {
+    static float* ptrs[64];
+    static std::mutex mu;
+    int dev = 0;
+    DVAE_HIP(hipGetDevice(&dev));
+    DVAE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        float* p = nullptr;
+        DVAE_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        DVAE_REQUIRE(p != nullptr && ((uintptr_t)p % 256) == 0, "static scratch: bad symbol address");
+        ptrs[dev] = p;
+    }
+    *out = ptrs[dev];
+    return DVAE_OK;
+}
+
+extern "C" int64_t dvae_decode_static_max_floats(void) { return (int64_t)DVAE_DECODE_STATIC_FLOATS; }
+
+extern "C" int dvae_decode_static(const dvae_model_desc* m, int32_t B, const float* pw, const float* z,
+                                  int32_t stochastic, const float* u_type, const float* u_edge, int32_t* types,
+                                  uint64_t* pred_mask, int32_t* n_vertices, void* stream) {
+    const int64_t need = dvae_decode_ws_floats(m, B);
+    DVAE_REQUIRE(need > 0, "dvae_decode_static: bad model descriptor or batch size %d", B);
+    DVAE_REQUIRE(need <= (int64_t)DVAE_DECODE_STATIC_FLOATS,
+                 "dvae_decode_static: %d graphs of this model need a workspace of %lld floats, the static scratch holds "
+                 "%lld; decode fewer graphs per call or use dvae_decode with a caller-provided workspace",
+                 B, (long long)need, (long long)DVAE_DECODE_STATIC_FLOATS);
+    float* ws = nullptr;
+    DVAE_TRY(static_scratch_for_current_device(&ws));
+    // (nothing in the workspace has to start at zero: decode_impl writes every word it later reads --
+    // running sums and gate buffers are cleared per vertex on the stream -- so the previous call's
+    // contents are harmless)
+    return decode_impl(m, B, pw, ws, z, stochastic, u_type, u_edge, types, pred_mask, n_vertices, stream);
 }

@@ -361,6 +361,21 @@ int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw, float* ws,
                 const float* u_type, const float* u_edge, int32_t* types, uint64_t* pred_mask, int32_t* n_vertices,
                 void* stream);
 
+/* dvae_decode for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops that turn latent points into graphs, harnesses that forbid hipMalloc).  It has NO
+ * counterpart in the reference.  Same arguments, outputs and results as dvae_decode, minus `ws`: the
+ * workspace is a fixed array of DVAE_DECODE_STATIC_FLOATS floats (32 MiB) inside the library's code
+ * object, one copy per GPU, held until the process ends.  The call allocates nothing and rejects a
+ * (model, B) whose dvae_decode_ws_floats exceeds that size (negative return, text in
+ * dvae_last_error()): e.g. B <= 263 at max_n = 8, hs = 501; B <= 20 at max_n = 64, hs = 1024.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; order them on one stream. */
+#define DVAE_DECODE_STATIC_FLOATS (8 * 1024 * 1024)
+int64_t dvae_decode_static_max_floats(void);
+int dvae_decode_static(const dvae_model_desc* m, int32_t B, const float* pw, const float* z, int32_t stochastic,
+                       const float* u_type, const float* u_edge, int32_t* types, uint64_t* pred_mask,
+                       int32_t* n_vertices, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
