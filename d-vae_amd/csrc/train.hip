@@ -92,39 +92,83 @@ __global__ void sum_scaled_kernel(const float* x, int n, const float* scale, flo
 // ------------------------------------------------------------------ side stream
 // The two encoder directions are independent chains of small dependent launches
 // (a level's GEMM fills at most half the chip).  They run concurrently: direction 0 on
-// the caller's stream, direction 1 on a per-device non-blocking side stream, forked and
-// joined with events, so the function's contract (all work ordered on the caller's
-// stream when it returns) is unchanged.  Stream and events are created once per device.
+// the caller's stream, direction 1 on a non-blocking side stream, forked and joined with
+// events, so the function's contract (all work ordered on the caller's stream when it
+// returns) is unchanged.
+// One side stream and event pair exists per (device, caller stream): calls on different caller
+// streams, from one host thread or several, never share events, so one call's fork cannot be
+// overwritten between its record and its wait by another call's (which would order that call's
+// side work behind the wrong point).  Calls on the SAME caller stream share the entry; their
+// records land on the one stream in issue order, so a wait can only pick up a LATER point of the
+// same stream: over-ordered, never under-ordered.  Entries are created on first use and recycled
+// least-recently-used beyond SIDE_CAP (hipStreamDestroy lets enqueued work finish).
 struct Side {
+    int dev = -1;
+    hipStream_t caller = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    unsigned long last_use = 0;
+    bool forked = false;  // per call: set by fork_side, cleared by join_side (SideGuard joins what an error path left open)
 };
-static int side_for_current_device(Side** out) {
-    static Side sides[64];
-    static std::mutex mu;
+constexpr int SIDE_CAP = 64;
+static std::mutex g_side_mu;
+static Side* g_sides[SIDE_CAP];
+static int g_nsides = 0;
+static unsigned long g_side_clock = 0;
+
+static int side_for_stream(hipStream_t caller, Side** out) {
     int dev = 0;
     DVAE_HIP(hipGetDevice(&dev));
-    DVAE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lock(mu);
-    Side& sd = sides[dev];
-    if (!sd.stream) {
-        DVAE_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-        DVAE_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-        DVAE_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    Side* sd = nullptr;
+    for (int i = 0; i < g_nsides; ++i)
+        if (g_sides[i]->dev == dev && g_sides[i]->caller == caller) sd = g_sides[i];
+    if (!sd) {
+        if (g_nsides < SIDE_CAP) {
+            sd = g_sides[g_nsides++] = new Side();
+        } else {  // recycle the entry that has been idle longest (its stream keeps running what it holds)
+            sd = g_sides[0];
+            for (int i = 1; i < g_nsides; ++i)
+                if (g_sides[i]->last_use < sd->last_use) sd = g_sides[i];
+            int cur = dev;
+            if (sd->dev != cur) DVAE_HIP(hipSetDevice(sd->dev));
+            (void)hipStreamDestroy(sd->stream);
+            (void)hipEventDestroy(sd->fork);
+            (void)hipEventDestroy(sd->join);
+            if (sd->dev != cur) DVAE_HIP(hipSetDevice(cur));
+            *sd = Side();
+        }
+        sd->dev = dev;
+        sd->caller = caller;
+        DVAE_HIP(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->join, hipEventDisableTiming));
     }
-    *out = &sd;
+    sd->last_use = ++g_side_clock;
+    *out = sd;
     return DVAE_OK;
 }
 static int fork_side(Side* sd, hipStream_t main) {
     DVAE_HIP(hipEventRecord(sd->fork, main));
     DVAE_HIP(hipStreamWaitEvent(sd->stream, sd->fork, 0));
+    sd->forked = true;
     return DVAE_OK;
 }
 static int join_side(Side* sd, hipStream_t main) {
+    sd->forked = false;
     DVAE_HIP(hipEventRecord(sd->join, sd->stream));
     DVAE_HIP(hipStreamWaitEvent(main, sd->join, 0));
     return DVAE_OK;
 }
+// Joins the side stream when an entry point leaves through an error return between a fork and its join:
+// whatever was enqueued on the side stream stays ordered before the caller's later work.
+struct SideGuard {
+    Side*& sd;
+    hipStream_t main;
+    ~SideGuard() {
+        if (sd && sd->forked) join_side(sd, main);
+    }
+};
 
 struct EncWs {
     float *agg[2], *gates[2], *ghn[2], *hs[2], *gm[2], *msg[2];
@@ -249,6 +293,14 @@ static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, co
 
 using namespace dvae;
 
+extern "C" int dvae_debug_side_stream(void* caller_stream, void** side_stream) {
+    DVAE_REQUIRE(side_stream != nullptr, "dvae_debug_side_stream: null output");
+    Side* sd = nullptr;
+    DVAE_TRY(side_for_stream((hipStream_t)caller_stream, &sd));
+    *side_stream = (void*)sd->stream;
+    return DVAE_OK;
+}
+
 extern "C" int64_t dvae_encode_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c) {
     Dims d;
     if (make_dims(m, d) != 0 || check_batch(d, c) != 0) return -1;
@@ -359,8 +411,9 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     // dvae_chain_level_batch, instead of two streams)
     const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
     Side* side = nullptr;
+    SideGuard side_guard{side, s};
     if (dirs == 2 && !merged) {
-        DVAE_TRY(side_for_current_device(&side));
+        DVAE_TRY(side_for_stream(s, &side));
         DVAE_TRY(fork_side(side, s));
     }
     if (d.bn) {
@@ -434,8 +487,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // two directions it runs on the (still idle) side stream under the head of this function, and the main
     // stream picks it up with the join below, long after it has finished
     Side* side = nullptr;
+    SideGuard side_guard{side, s};
     if (dirs == 2) {
-        DVAE_TRY(side_for_current_device(&side));
+        DVAE_TRY(side_for_stream(s, &side));
         DVAE_TRY(fork_side(side, s));
         DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40,
                                side->stream));
@@ -613,7 +667,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     static const int by_level_knob = [] { const char* v = getenv("DVAE_BY_LEVEL"); return v ? atoi(v) : 1; }();
     const bool by_level = !d.bn && c->level_major != 0 && by_level_knob != 0;
     Side* side = nullptr;
-    if (by_level) DVAE_TRY(side_for_current_device(&side));
+    SideGuard side_guard{side, s};
+    if (by_level) DVAE_TRY(side_for_stream(s, &side));
     DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
     DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
@@ -740,7 +795,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     // The predictors' weight gradients depend only on what is already computed; they run on the
     // side stream while the main stream continues into the (latency-bound) state chain.
     Side* side = nullptr;
-    DVAE_TRY(side_for_current_device(&side));
+    SideGuard side_guard{side, s};
+    DVAE_TRY(side_for_stream(s, &side));
     DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
     // vertex-type predictor, data path (main stream)
     EW(scaled_copy_kernel, (long)c->R * d.Tp, w.dlogits_s, w.dlogits, g_res, (long)c->R * d.Tp);

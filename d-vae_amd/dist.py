@@ -52,9 +52,37 @@ class GradSumReducer(object):
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
         self._early = None
+        self.extra_params = []
         # backward() then adds straight into these views (no autograd accumulation kernels)
         if sink and hasattr(model, "attach_grad_sink") and self.flat.is_cuda:
             model.attach_grad_sink(True, self)
+
+    def add_extra(self, params):
+        """Parameters outside the flat buffer whose gradients must be summed over the ranks as well: the optional
+        predictor head (train.py:165-172), whose MSE loss is a SUM over the rank's graphs (reduction='sum').
+        Their .grad tensors are owned by autograd; all_reduce() exchanges them coalesced in one more small
+        all-reduce."""
+        have = {id(p) for p in self.extra_params} | {id(p) for p in self.params}
+        self.extra_params += [p for p in params if id(p) not in have]
+
+    def _reduce_extra(self):
+        grads = [p.grad for p in self.extra_params if p.grad is not None]
+        if not grads:
+            return
+        if len(grads) != len(self.extra_params):
+            raise RuntimeError("some extra parameters have no gradient on this rank: the ranks would disagree on "
+                               "what to exchange")
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat = host.to(flat.device)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
 
     @staticmethod
     def _collective():
@@ -84,6 +112,8 @@ class GradSumReducer(object):
     def all_reduce(self):
         if not self._collective():
             return
+        if self.extra_params:
+            self._reduce_extra()
         if self.flat.is_cuda and dist.get_backend() == "gloo":
             # rehearsal path (several ranks sharing one GPU): gloo reduces on the host
             host = self.flat.cpu()

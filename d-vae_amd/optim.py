@@ -24,6 +24,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.extra = torch.optim.Adam(extra, lr=lr, betas=betas, eps=eps) if extra else None
         self.reducer = reducer if reducer is not None else GradSumReducer(model)
         r = self.reducer
+        r.add_extra(extra)  # their gradients join the exchange step (the head's loss is a sum over the rank's graphs too)
         if not r.flat.is_cuda:
             raise _lib.DvaeHipError("FlatAdam runs on a HIP device; move the model first (no CPU fallback)")
         super(FlatAdam, self).__init__(r.params, dict(lr=lr, betas=betas, eps=eps))
@@ -69,13 +70,87 @@ class FlatAdam(torch.optim.Optimizer):
             self.extra.step()
         return loss
 
+    # ------------------------------------------------------------------ checkpoints
+    # The layout written and read is torch.optim.Adam's own (what the reference saves as
+    # optimizer_checkpoint<epoch>.pth, train.py:705-712, and loads back with --continue-from, train.py:185-192):
+    #   {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [0 .. N-1]}]}
+    # with i numbering `model.parameters()` in order (the reference builds optim.Adam(model.parameters())),
+    # parameters that never received a gradient having no entry.  So a reference run resumes here and a run
+    # of this package resumes under torch.optim.Adam.
+    def _ordered_params(self):
+        params = list(self.model.parameters())
+        seen = {id(p) for p in params}
+        if self.extra is not None:  # extra parameters that are not sub-modules of the model come last
+            params += [p for g in self.extra.param_groups for p in g["params"] if id(p) not in seen]
+        return params
+
     def state_dict(self):
-        return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "names": list(self.reducer.names), "offsets": list(self.reducer.offsets),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "extra": self.extra.state_dict() if self.extra is not None else None}
+        r = self.reducer
+        slot = {id(p): (o, p.numel()) for p, o in zip(r.params, r.offsets)}
+        state = {}
+        extra_state = {id(k): v for k, v in self.extra.state.items()} if self.extra is not None else {}
+        for i, p in enumerate(self._ordered_params()):
+            if id(p) in slot:
+                if self.steps > 0:
+                    o, n = slot[id(p)]
+                    state[i] = {"step": torch.tensor(float(self.steps)),
+                                "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                                "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+            elif id(p) in extra_state:
+                state[i] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in extra_state[id(p)].items()}
+        probe = torch.zeros(1, requires_grad=True)
+        group = dict(torch.optim.Adam([probe]).state_dict()["param_groups"][0])  # this torch version's keys and defaults
+        mine = self.param_groups[0]
+        group.update(lr=mine["lr"], betas=tuple(mine["betas"]), eps=mine["eps"])
+        for k in ("initial_lr",):  # what a scheduler attached to this optimizer left in the group
+            if k in mine:
+                group[k] = mine[k]
+        group["params"] = list(range(len(self._ordered_params())))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        if "names" in sd and "state" not in sd:
+            return self._load_flat_state(sd)  # files written by the first version of this class
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("not an Adam state dict (expected the keys 'state' and 'param_groups')")
+        params = self._ordered_params()
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(params):
+            raise ValueError("optimizer state covers %d parameters, the model has %d" % (len(ids), len(params)))
+        r = self.reducer
+        slot = {id(p): (o, p.numel()) for p, o in zip(r.params, r.offsets)}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = 0
+        extra_state = {}
+        for i, p in zip(ids, params):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state %d has shape %s, the parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            if id(p) in slot:
+                o, n = slot[id(p)]
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps = max(steps, int(float(st["step"])))
+            else:
+                extra_state[id(p)] = st  # a parameter outside the hot path (predictor head), or one the step never touches
+        self.steps = steps
+        saved = sd["param_groups"][0]
+        g = self.param_groups[0]
+        g.update(lr=saved["lr"], betas=tuple(saved["betas"]), eps=saved["eps"])
+        if "initial_lr" in saved:
+            g["initial_lr"] = saved["initial_lr"]
+        if self.extra is not None:
+            own = self.extra.state_dict()
+            eparams = [p for eg in self.extra.param_groups for p in eg["params"]]
+            own["state"] = {j: extra_state[id(p)] for j, p in enumerate(eparams) if id(p) in extra_state}
+            for eg in own["param_groups"]:
+                eg.update(lr=saved["lr"], betas=tuple(saved["betas"]), eps=saved["eps"])
+            self.extra.load_state_dict(own)
+
+    def _load_flat_state(self, sd):
         if list(sd["names"]) != list(self.reducer.names):
             raise ValueError("optimizer state belongs to a different parameter set")
         self.steps = int(sd["steps"])

@@ -327,6 +327,15 @@ void dvae_batch_destroy(void* handle);
 int64_t dvae_encode_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c);
 int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c);
 
+/* Concurrency.  The four entry points below run part of their work on an internal side stream (the second
+ * encoder direction, the predictors' products and weight gradients), forked from and joined back into the
+ * caller's stream with events, so that on return everything is ordered on the caller's stream.  Side stream
+ * and events are kept per (device, caller stream): calls on different streams -- from one host thread or
+ * several -- are independent of each other; calls that share one stream are ordered by it as usual.  A
+ * workspace belongs to one call at a time.  dvae_debug_side_stream reports the side stream the library pairs
+ * with a caller stream on the current device (diagnostics / tests; no counterpart in the reference). */
+int dvae_debug_side_stream(void* caller_stream, void** side_stream);
+
 /* DVAE.encode, models.py:720-731 (DVAE_BN.encode :1068-1080): mu, logvar [B][nz] */
 int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
                         float* ws, float* mu, float* logvar, void* stream);

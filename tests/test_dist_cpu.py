@@ -46,6 +46,11 @@ def _worker(rank, world, port, path, out, balance):
     eps = torch.from_numpy(d["eps"])[lo:hi]  # rank r uses its rows of the global normal draw
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     L, _, _, _, _, grads = O.train_step_grads(cfg_of(cls, ctor), sd, types, adj, n_g, eps)
+    # a parameter outside the flat buffer (the predictor head of train.py:165-172): its gradient is exchanged too
+    head = torch.nn.Linear(3, 1)
+    reducer.add_extra(list(head.parameters()))
+    for p in head.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
     reducer.zero()
     named = dict(model.named_parameters())
     for k, g in grads.items():
@@ -54,6 +59,8 @@ def _worker(rank, world, port, path, out, balance):
         else:
             named[k].grad += g                        # what autograd's accumulation does after backward()
     reducer.all_reduce()
+    for p in head.parameters():
+        assert torch.equal(p.grad, torch.full_like(p, 3.0))  # 1 + 2 over the two ranks
     loss = reducer.reduce_scalars(L)[0].float()       # the logging all-reduce
     if rank == 0:
         torch.save({"loss": loss, "grads": {k: (p.grad.clone() if p.grad is not None else None)

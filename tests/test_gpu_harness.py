@@ -74,3 +74,67 @@ def test_predictor_head_and_list_of_pairs_dataset():
     assert len(first) == 4 and last[0] < first[0] and last[3] < first[3]
     nll, acc, rmse = H.test(model, pairs, 32, 1, 1, predictor=True)
     assert np.isfinite(nll) and np.isfinite(rmse)
+
+
+def test_optimizer_checkpoints_are_torch_adam_checkpoints(tmp_path):
+    """The reference saves optimizer.state_dict() of torch.optim.Adam(model.parameters()) per epoch and resumes from it
+    (train.py:174, 705-712, 185-192).  FlatAdam reads and writes exactly that layout: a run started under torch's Adam
+    continues under FlatAdam from the file the reference would have written, and the other way round, with the
+    same parameters afterwards as an uninterrupted torch-Adam run -- predictor head and ReduceLROnPlateau included."""
+    import numpy as np
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    rng = np.random.default_rng(3)
+    ctor = dict(max_n=8, nvt=8, START_TYPE=0, END_TYPE=1, hs=40, nz=8, bidirectional=True)
+    rows = dvae_amd.data.synth_enas_rows(24, 6, 6, 0.3, 4)
+    ga = dvae_amd.data.enas_rows_to_arrays(rows, 8)
+    eps = torch.from_numpy(rng.standard_normal((24, 8)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.standard_normal((24, 1)).astype(np.float32)).cuda()
+
+    def build(flat):
+        torch.manual_seed(11)
+        m = dvae_amd.DVAE(**ctor)
+        m.predictor = nn.Sequential(nn.Linear(8, 16), nn.Tanh(), nn.Linear(16, 1))
+        m.mseloss = nn.MSELoss(reduction="sum")
+        m.cuda().train()
+        if flat:
+            o = dvae_amd.optim.FlatAdam(m, lr=1e-3, extra_params=m.predictor.parameters())
+        else:
+            o = torch.optim.Adam(m.parameters(), lr=1e-3)
+        return m, o, ReduceLROnPlateau(o, "min", factor=0.1, patience=10)
+
+    def steps(m, o, k):
+        for _ in range(k):
+            o.zero_grad()
+            mu, lv = m.encode(ga)
+            loss, _, _ = m.loss(mu, lv, ga, eps=eps)
+            loss = loss + m.mseloss(m.predictor(mu), y)
+            loss.backward()
+            o.step()
+
+    ref_m, ref_o, _ = build(False)
+    start = {k: v.detach().clone() for k, v in ref_m.state_dict().items()}
+    steps(ref_m, ref_o, 5)  # the uninterrupted run
+    want = {k: v.detach().clone() for k, v in ref_m.state_dict().items()}
+
+    for first_flat in (False, True):
+        m1, o1, s1 = build(first_flat)
+        steps(m1, o1, 3)
+        s1.step(123.0)
+        H.save_checkpoint(str(tmp_path), 3, m1, o1, s1)
+        saved = torch.load(str(tmp_path / "optimizer_checkpoint3.pth"), weights_only=True)
+        names = [k for k, _ in m1.named_parameters()]
+        assert sorted(saved.keys()) == ["param_groups", "state"] and saved["param_groups"][0]["params"] == list(range(len(names)))
+        assert "hv_unify.0.weight" in names and names.index("hv_unify.0.weight") not in saved["state"]  # never had a gradient
+        m2, o2, s2 = build(not first_flat)
+        H.load_module_state(m2, str(tmp_path / "model_checkpoint3.pth"))
+        H.load_module_state(o2, str(tmp_path / "optimizer_checkpoint3.pth"))
+        H.load_module_state(s2, str(tmp_path / "scheduler_checkpoint3.pth"))
+        assert s2.best == 123.0
+        steps(m2, o2, 2)
+        got = m2.state_dict()
+        # Adam divides by sqrt(v): where a gradient entry is rounding noise of the atomics' summation order, its
+        # update is +-lr whatever the noise, so single entries may differ by a few lr between two correct runs; the
+        # bar is norm-wise on what the five steps moved (and a wrong or missing moment moves everything)
+        for k in want:
+            moved = (want[k] - start[k]).norm().item()
+            assert (got[k] - want[k]).norm().item() <= 2e-3 * moved + 1e-7, (first_flat, k, (got[k] - want[k]).abs().max().item())

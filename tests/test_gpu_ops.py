@@ -827,3 +827,51 @@ def test_type_csr_and_type_colsum_match_torch(rows, nb, Hp, T):
     scale = max(1.0, n ** 0.5)
     assert (gi.double() - ref_gi).abs().max() < 2e-5 * scale
     assert (bhn.double() - ref_bhn).abs().max() < 2e-5 * scale
+
+
+def test_side_streams_are_per_caller_stream_and_concurrent_calls_are_independent():
+    """The entry points fork part of their work onto an internal side stream.  It is keyed by (device, caller
+    stream): two caller streams never share one (nor its fork / join events), so two host threads driving two
+    streams at once get the results of the same calls made one after the other."""
+    import threading
+    import numpy as np
+    from common import make_model
+    lib = L.load()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    side = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+    for st, out in ((s1, side[0]), (s2, side[1]), (s1, side[2])):
+        L.check(lib.dvae_debug_side_stream(C.c_void_p(st.cuda_stream), C.byref(out)), "side stream")
+    assert side[0].value != side[1].value and side[0].value == side[2].value
+    assert side[0].value not in (s1.cuda_stream, s2.cuda_stream)
+
+    ctor = dict(max_n=8, nvt=8, START_TYPE=0, END_TYPE=1, hs=72, nz=10, bidirectional=1)
+    model = make_model("DVAE", ctor, 3).cuda().train()
+    rows = [dvae_amd.data.synth_enas_rows(96, 6, 6, 0.3, sd) for sd in (1, 2)]
+    gas = [dvae_amd.data.enas_rows_to_arrays(r, 8) for r in rows]
+    batches = [model._collate_fn(g) for g in gas]
+    eps = [torch.randn(96, 10, device="cuda") for _ in gas]
+    model._packed_weights()
+    torch.cuda.synchronize()
+
+    def run(i, stream, out, reps):
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                mu, lv = model.encode(batches[i])
+                loss, _, _ = model.loss(mu, lv, batches[i], eps=eps[i])
+                g = torch.autograd.grad(loss, [model.grud.weight_hh, model.grue_backward.weight_hh])
+            stream.synchronize()
+        out[i] = (loss.item(), mu.detach().clone(), [x.clone() for x in g])
+
+    serial, conc = {}, {}
+    run(0, s1, serial, 1)
+    run(1, s2, serial, 1)
+    th = [threading.Thread(target=run, args=(i, st, conc, 6)) for i, st in ((0, s1), (1, s2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in (0, 1):
+        assert abs(conc[i][0] - serial[i][0]) <= 1e-6 * abs(serial[i][0])
+        assert torch.equal(conc[i][1], serial[i][1])  # forward results are bit-reproducible
+        for a, b in zip(conc[i][2], serial[i][2]):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max()  # split-K sums arrive in any order
