@@ -102,6 +102,16 @@ def graphs_to_arrays(graphs, max_n):
     return GraphArrays(types, mask, n_g, max_n)
 
 
+_COPY_STREAMS = {}
+
+
+def _copy_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COPY_STREAMS[key]
+
+
 class DAGBatch(object):
     """A packed batch: host arrays + the device index blob the kernels read."""
 
@@ -121,14 +131,34 @@ class DAGBatch(object):
                                          _lib.ptr(arrays.n_vertices), C.byref(handle), C.byref(counts)),
                    "dvae_batch_create")
         try:
-            host = torch.empty(int(counts.total_ints), dtype=torch.int32)
+            self.device = torch.device(device)
+            on_gpu = self.device.type == "cuda"
+            # pinned staging: the copy below is then a true asynchronous DMA instead of a staged pageable copy
+            host = torch.empty(int(counts.total_ints), dtype=torch.int32, pin_memory=on_gpu)
             _lib.check(lib.dvae_batch_export(handle, host.data_ptr(), counts.total_ints), "dvae_batch_export")
         finally:
             lib.dvae_batch_destroy(handle)
         self.counts = counts
         self.blob_host = host
-        self.device = torch.device(device)
-        self.blob = host.to(self.device, non_blocking=False) if self.device.type == "cuda" else None
+        self.blob = None
+        self.ready = None
+        if on_gpu:
+            # The copy runs on a copy stream of its own, so a batch packed ahead of time (harness prefetch thread)
+            # does not queue behind the compute already enqueued; consumers wait on `ready` (wait_ready()).
+            with torch.cuda.device(self.device):
+                cs = _copy_stream(self.device)
+                with torch.cuda.stream(cs):
+                    self.blob = host.to(self.device, non_blocking=True)
+                    self.ready = torch.cuda.Event()
+                    self.ready.record(cs)
+
+    def wait_ready(self):
+        """orders the current stream behind the blob's host-to-device copy (until the copy is known to be done)"""
+        if self.ready is not None:
+            if self.ready.query():
+                self.ready = None
+            else:
+                torch.cuda.current_stream(self.device).wait_event(self.ready)
 
     def __len__(self):
         return self.B

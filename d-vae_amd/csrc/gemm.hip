@@ -430,7 +430,7 @@ static int env_int(const char* name) {
     return v ? atoi(v) : 0;
 }
 
-int gemm(const dvae_gemm_desc& d, hipStream_t s) {
+int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
     static const int knob_log = env_int("DVAE_GEMM_LOG"), knob_tile = env_int("DVAE_GEMM_TILE"),
                      knob_split = env_int("DVAE_GEMM_SPLIT");
     DVAE_TRY(gemm_check(d, 32));
@@ -445,7 +445,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
         if (kc < d.K) {
             dvae_gemm_desc sub;
             int k0 = 0;
-            while (gemm_next_chunk(d, kc, k0, sub)) DVAE_TRY(gemm(sub, s));
+            while (gemm_next_chunk(d, kc, k0, sub)) DVAE_TRY(gemm(sub, s, max_split));
             return DVAE_OK;
         }
     }
@@ -478,7 +478,8 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s) {
     int best = 1;
     {
         double best_cost = -1.0;
-        const int maxsplit = may_split ? (ksteps / 4 < 16 ? ksteps / 4 : 16) : 1;
+        int maxsplit = may_split ? (ksteps / 4 < 16 ? ksteps / 4 : 16) : 1;
+        if (max_split > 0 && maxsplit > max_split) maxsplit = max_split;
         for (int big = 0; big < 2; ++big) {
             const long tiles = big ? t128 : t64;
             for (int sk = 1; sk <= maxsplit; ++sk) {
@@ -533,5 +534,5 @@ extern "C" int dvae_debug_set_kmajor_span_limit(int64_t bytes) {
 
 extern "C" int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream) {
     if (!d) return dvae::set_err(DVAE_ERR_ARG, "dvae_gemm_f32: null descriptor");
-    return dvae::gemm(*d, (hipStream_t)stream);
+    return dvae::gemm(*d, (hipStream_t)stream, 0);
 }

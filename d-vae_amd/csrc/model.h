@@ -83,7 +83,7 @@ static inline PackedLayout make_layout(const Dims& d) {
 }
 
 // internal kernels shared between translation units
-int gemm(const dvae_gemm_desc& d, hipStream_t s);
+int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split = 0);  // max_split > 0 caps the split-K factor
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);
 int scale_inplace(float* x, const float* s, int n, hipStream_t st);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,

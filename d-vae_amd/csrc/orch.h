@@ -11,7 +11,9 @@ namespace dvae {
 // Matrix-unit input type of the call in progress (dvae_model_desc.mfma_bf16), set by every
 // entry point before it enqueues anything.
 static thread_local int tl_bf16 = 0;
-static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s) { return tl_bf16 ? gemm_bf16(g, s) : gemm(g, s); }
+static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s, int max_split = 0) {
+    return tl_bf16 ? gemm_bf16(g, s) : gemm(g, s, max_split);
+}
 
 // Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
 static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
@@ -33,11 +35,11 @@ static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* d
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
 // xrows (nullable) gathers the rows of X; xrows_bound = rows of the stored X the list may name
 static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
-                     int N, int K, hipStream_t s, int xrows_bound = 0) {
+                     int N, int K, hipStream_t s, int xrows_bound = 0, int max_split = 0) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
     g.M = N; g.N = K; g.K = M; g.accumulate = 1; g.b_rows_bound = xrows_bound;
-    return run_gemm(g, s);
+    return run_gemm(g, s, max_split);
 }
 
 struct Bump {

@@ -107,6 +107,10 @@ struct Side {
     hipStream_t caller = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    // third stream: the weight-gradient chunks of the encoder's backward chains (both other streams walk a chain there)
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_ev = nullptr, aux_join = nullptr;
+    bool aux_open = false;  // work enqueued on aux since the last join_aux
     unsigned long last_use = 0;
     bool forked = false;  // per call: set by fork_side, cleared by join_side (SideGuard joins what an error path left open)
 };
@@ -135,14 +139,25 @@ static int side_for_stream(hipStream_t caller, Side** out) {
             (void)hipStreamDestroy(sd->stream);
             (void)hipEventDestroy(sd->fork);
             (void)hipEventDestroy(sd->join);
+            (void)hipStreamDestroy(sd->aux);
+            (void)hipEventDestroy(sd->aux_ev);
+            (void)hipEventDestroy(sd->aux_join);
             if (sd->dev != cur) DVAE_HIP(hipSetDevice(cur));
             *sd = Side();
         }
         sd->dev = dev;
         sd->caller = caller;
-        DVAE_HIP(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
+        static const int prio_knob = [] { const char* v = getenv("DVAE_SIDE_PRIO"); return v ? atoi(v) : 0; }();
+        int plo = 0, phi = 0;  // numerically greatest = lowest priority
+        DVAE_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        if (prio_knob & 1) DVAE_HIP(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, plo));
+        else DVAE_HIP(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
         DVAE_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
         DVAE_HIP(hipEventCreateWithFlags(&sd->join, hipEventDisableTiming));
+        if (prio_knob & 2) DVAE_HIP(hipStreamCreateWithPriority(&sd->aux, hipStreamNonBlocking, plo));
+        else DVAE_HIP(hipStreamCreateWithFlags(&sd->aux, hipStreamNonBlocking));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_ev, hipEventDisableTiming));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_join, hipEventDisableTiming));
     }
     sd->last_use = ++g_side_clock;
     *out = sd;
@@ -160,6 +175,21 @@ static int join_side(Side* sd, hipStream_t main) {
     DVAE_HIP(hipStreamWaitEvent(main, sd->join, 0));
     return DVAE_OK;
 }
+// aux stream: `after(producer)` orders everything enqueued on aux from now on behind what `producer` holds now
+// (a stream wait captures the event's latest record at the time of the call, so one event serves every hand-off)
+static int aux_after(Side* sd, hipStream_t producer) {
+    DVAE_HIP(hipEventRecord(sd->aux_ev, producer));
+    DVAE_HIP(hipStreamWaitEvent(sd->aux, sd->aux_ev, 0));
+    sd->aux_open = true;
+    return DVAE_OK;
+}
+static int join_aux(Side* sd, hipStream_t main) {
+    if (!sd->aux_open) return DVAE_OK;
+    sd->aux_open = false;
+    DVAE_HIP(hipEventRecord(sd->aux_join, sd->aux));
+    DVAE_HIP(hipStreamWaitEvent(main, sd->aux_join, 0));
+    return DVAE_OK;
+}
 // Joins the side stream when an entry point leaves through an error return between a fork and its join:
 // whatever was enqueued on the side stream stays ordered before the caller's later work.
 struct SideGuard {
@@ -167,6 +197,7 @@ struct SideGuard {
     hipStream_t main;
     ~SideGuard() {
         if (sd && sd->forked) join_side(sd, main);
+        if (sd && sd->aux_open) join_aux(sd, main);
     }
 };
 
@@ -274,19 +305,28 @@ static int check_batch(const Dims& d, const dvae_batch_counts* c) {
     return DVAE_OK;
 }
 
-// weight gradients shared by every GRU pass: dWhh, d gi_tab, d bhn
-// (rows [zero_lo, zero_hi) have h_prev = 0 -- the first level of an encoder pass -- and are left out of dWhh)
-static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
-                      const float* agg, const float* xoh, int rows, hipStream_t s, int zero_lo = 0, int zero_hi = 0) {
+// weight gradients shared by every GRU pass: dWhh over the rows [lo, hi) (the passes call it level by level, as soon
+// as a level's d gh is final, on a stream beside the chain), and d gi_tab, d bhn over all rows at the end
+static int gru_whh_wgrad(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* agg,
+                         long lo, long hi, hipStream_t s, int max_split = 0) {
     const int Hp = d.Hp;
-    const int lo = zero_lo == 0 ? zero_hi : 0, hi = zero_hi == rows && zero_lo > 0 ? zero_lo : rows;  // a prefix or a suffix
-    DVAE_TRY(lin_wgrad(dgh + (size_t)lo * 3 * Hp, 3 * Hp, agg + (size_t)lo * Hp, Hp, nullptr, pg + L.whh[g], Hp, hi - lo,
-                       3 * Hp, Hp, s));
+    if (hi <= lo) return DVAE_OK;
+    return lin_wgrad(dgh + (size_t)lo * 3 * Hp, 3 * Hp, agg + (size_t)lo * Hp, Hp, nullptr, pg + L.whh[g], Hp, (int)(hi - lo),
+                     3 * Hp, Hp, s, 0, max_split);
+}
+static int gru_type_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
+                           const float* xoh, int rows, hipStream_t s) {
     // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin; d bhn = column sum of
     // dgh's n block: one sweep over the rows sorted by type (instead of two one-hot products and a column sum)
     const int* tcsr = reinterpret_cast<const int*>(xoh);
-    DVAE_TRY(dvae_type_colsum(dgh, dgin, tcsr, tcsr + 40, d.T, pg + L.gi[g], pg + L.bhn[g], rows, Hp, s));
-    return DVAE_OK;
+    return dvae_type_colsum(dgh, dgin, tcsr, tcsr + 40, d.T, pg + L.gi[g], pg + L.bhn[g], rows, d.Hp, s);
+}
+// (rows [zero_lo, zero_hi) have h_prev = 0 -- the first level of an encoder pass -- and are left out of dWhh)
+static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
+                      const float* agg, const float* xoh, int rows, hipStream_t s, int zero_lo = 0, int zero_hi = 0) {
+    const int lo = zero_lo == 0 ? zero_hi : 0, hi = zero_hi == rows && zero_lo > 0 ? zero_lo : rows;  // a prefix or a suffix
+    DVAE_TRY(gru_whh_wgrad(d, L, g, pg, dgh, agg, lo, hi, s));
+    return gru_type_wgrads(d, L, g, pg, dgh, dgin, xoh, rows, s);
 }
 
 }  // namespace dvae
@@ -339,6 +379,25 @@ static bool chain_merge_dirs() {
 static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
     return (knob == 2 || (knob == 1 && chain_level_small(d, B))) && !d.bf16 && !d.bn;
+}
+
+// The weight gradients of a backward chain (dWhh, d[Wg|Wm]) are sums over levels: each level's term is enqueued on a
+// stream beside the chain as soon as that level's d gh / d gm is final, where it fills the matrix-unit time the
+// latency-bound level kernels leave idle, instead of as whole-pass products after the chain with nothing beside them
+// (decoder: 0.45 ms of idle side stream under the chain, then 0.2 ms of products alone).
+// Measured (cfg 2, same box, interleaved runs): decoder pass 4.086 -> 4.058 ms per step; the encoder's two passes, whose
+// chains already occupy two streams, LOSE with a third stream of per-level terms (4.06 -> 4.33 ms: the small products
+// delay the level kernels they share CUs with), so the default is the decoder only.  Capping the terms' split-K at 1
+// (fewer workgroups, no atomics) and a low-priority side stream were measured too: 4.16 ms and no change.
+// DVAE_WGRAD_BY_LEVEL: bit 0 decoder, bit 1 encoder (default 1; 0 = whole-pass products after the chains).
+static int wbl_knob() {
+    static const int knob = [] { const char* v = getenv("DVAE_WGRAD_BY_LEVEL"); return v ? atoi(v) : 1; }();
+    return knob;
+}
+static bool wgrad_by_level(int which = 1) { return (wbl_knob() & which) != 0; }
+static int wbl_split() {
+    static const int knob = [] { const char* v = getenv("DVAE_WBL_SPLIT"); return v ? atoi(v) : 0; }();
+    return knob;
 }
 
 // =====================================================================================
@@ -488,8 +547,13 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // stream picks it up with the join below, long after it has finished
     Side* side = nullptr;
     SideGuard side_guard{side, s};
+    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
+    // per-level weight-gradient terms beside the chains: on the (idle) side stream with one direction, on a third
+    // stream with two (both other streams walk a chain)
+    const bool wbl = !d.bn && !merged && wgrad_by_level(2);
+    if (dirs == 2 || wbl) DVAE_TRY(side_for_stream(s, &side));
+    hipStream_t wg_stream = wbl ? (dirs == 2 ? side->aux : side->stream) : nullptr;
     if (dirs == 2) {
-        DVAE_TRY(side_for_stream(s, &side));
         DVAE_TRY(fork_side(side, s));
         DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40,
                                side->stream));
@@ -570,16 +634,31 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         } else if (step > 0)
             DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
                                3 * Hp, Hp, 1, s));
+        if (wbl) {
+            // final now: d gh of this level; d gm of the level processed next (fused: the tail above) or of this one
+            if (dirs == 2) DVAE_TRY(aux_after(side, s));
+            else DVAE_TRY(fork_side(side, s));
+            if (step > 0)  // (the pass's first level has h_prev = 0: no term)
+                DVAE_TRY(gru_whh_wgrad(d, L, k, pg, w.dgh[k], w.agg[k], r0, r0 + B, wg_stream, wbl_split()));
+            const int sg = fused ? step - 1 : step;  // forward-pass step of the level whose d gm is final
+            if (sg >= 0 && sg < n - 1) {
+                const long rg = (long)(k == 0 ? sg : n - 1 - sg) * B;
+                DVAE_TRY(lin_wgrad(w.dgm[k] + rg * 2 * Hp, 2 * Hp, w.hs[k] + rg * Hp, Hp, nullptr, pg + L.wgm[k], Hp, B,
+                                   2 * Hp, Hp, wg_stream, 0, wbl_split()));
+            }
+        }
         return DVAE_OK;
     };
     auto end_dir = [&](int k, hipStream_t s) -> int {
         if (!d.bn) {
             // (d gm of the pass's last vertex is zero -- no message leaves it: those B rows are left out)
             const size_t o = k == 0 ? 0 : (size_t)B;
-            DVAE_TRY(lin_wgrad(w.dgm[k] + o * 2 * Hp, 2 * Hp, w.hs[k] + o * Hp, Hp, nullptr, pg + L.wgm[k], Hp, nB - B,
-                               2 * Hp, Hp, s));
+            if (!wbl)
+                DVAE_TRY(lin_wgrad(w.dgm[k] + o * 2 * Hp, 2 * Hp, w.hs[k] + o * Hp, Hp, nullptr, pg + L.wgm[k], Hp, nB - B,
+                                   2 * Hp, Hp, s));
             DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
+        if (wbl) return gru_type_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.xoh, nB, s);
         // DVAE: the pass's first level (vertex 0 forward, vertex n-1 backward) has no predecessors, h_prev = 0
         const int z_lo = d.bn ? 0 : (k == 0 ? 0 : nB - B), z_hi = d.bn ? 0 : (k == 0 ? B : nB);
         DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s, z_lo, z_hi));
@@ -587,7 +666,6 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     };
     // as in the forward pass: two streams, enqueued level by level in turn
     // (as in the forward pass: optionally both directions of a level as one grid)
-    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
     if (dirs == 2) DVAE_TRY(join_side(side, s));  // the type sort (csr_on_side)
     if (dirs == 2 && !merged) {
         DVAE_TRY(fork_side(side, s));
@@ -637,7 +715,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     }
     if (dirs == 2) DVAE_TRY(end_dir(1, side->stream));
     DVAE_TRY(end_dir(0, s));
-    if (dirs == 2) DVAE_TRY(join_side(side, s));
+    if (dirs == 2 || (side && side->forked)) DVAE_TRY(join_side(side, s));
+    if (side) DVAE_TRY(join_aux(side, s));
     return DVAE_OK;
 }
 
@@ -844,6 +923,12 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
         // (only the last vertex's rows of d gm are not written by the chain below)
         DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
+        const bool wbl = wgrad_by_level();
+        hipStream_t s2 = side->stream;
+        if (wbl) {  // the partial rows' d gh is final: their term of dWhh starts the side stream's run beside the chain
+            DVAE_TRY(fork_side(side, s));
+            DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2));
+        }
         for (int v = n - 1; v >= 0; --v) {
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
@@ -875,12 +960,22 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                 DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
             } else
                 DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
+            if (wbl) {
+                // final now: d gh of vertex v, and d gm of vertex v - 1 (fused: the tail above) or v (unfused: this iteration)
+                const int vg = fused ? v - 1 : v;
+                DVAE_TRY(fork_side(side, s));
+                DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + B, s2, wbl_split()));
+                if (vg >= 0 && vg < n - 1)  // (d gm of the last vertex is zero: no message leaves it)
+                    DVAE_TRY(lin_wgrad(w.dgm + (size_t)vg * B * 2 * Hp, 2 * Hp, w.st + (size_t)vg * B * Hp, Hp, nullptr,
+                                       pg + L.wgm[0], Hp, B, 2 * Hp, Hp, s2, 0, wbl_split()));
+            }
         }
     }
-    // the GRU's weight gradients (the largest products of this tail) go to the side stream, behind
-    // the predictors' (long finished); the gate/mapper ones and the head stay here
+    // the GRU's remaining weight gradients go to the side stream, behind the predictors' and the per-level terms
     DVAE_TRY(fork_side(side, s));
-    DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
+    const bool wbl_done = !d.bn && wgrad_by_level();
+    if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream));
+    else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
     // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------
     EW(tanh_bwd_kernel, (long)B * Hp, w.dagg, w.agg, (long)B * Hp);
     DVAE_TRY(dvae_segment_colsum_f32(pg + L.b3, Hp, w.dagg, Hp, B, B, Hp, s));
@@ -889,7 +984,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
     if (!d.bn) {
         // (d gm of the last vertex is zero: left out)
-        DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s));
+        if (!wbl_done) DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
     }
     DVAE_TRY(join_side(side, s));

@@ -49,7 +49,18 @@ def _packed_batches(model, ga, order, batch_size, prefetch):
     import queue
     import threading
     q = queue.Queue(maxsize=3)
+    stop = threading.Event()
     dev = model.get_device()
+
+    def put(item):
+        """blocks while the queue is full, but gives up when the consumer has gone away"""
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def work():
         try:
@@ -57,21 +68,32 @@ def _packed_batches(model, ga, order, batch_size, prefetch):
                 torch.cuda.set_device(dev)
             for lo, hi in spans:
                 idx = order[lo:hi]
-                q.put((idx, model._collate_fn(ga.select(idx))))
-            q.put(None)
+                if not put((idx, model._collate_fn(ga.select(idx)))):
+                    return
+            put(None)
         except BaseException as e:  # surfaces in the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is None:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        yield item
-    t.join()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        # the consumer stopped (end of data, an exception in the training step, or the generator was closed):
+        # release the worker and the batches it still holds
+        stop.set()
+        while True:
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                break
+        t.join()
 
 
 def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predictor=False, reducer=None,

@@ -68,6 +68,7 @@ class _EncodeFn(torch.autograd.Function):
         lib = _lib.load()
         dev = params[0].device
         pw = model._packed_weights()
+        batch.wait_ready()
         B = batch.B
         n_ws = lib.dvae_encode_ws_floats(C.byref(model._desc), C.byref(batch.counts))
         if n_ws < 0:
@@ -103,6 +104,7 @@ class _LossFn(torch.autograd.Function):
         lib = _lib.load()
         dev = params[0].device
         pw = model._packed_weights()
+        batch.wait_ready()
         mu_c, lv_c = mu.contiguous().float(), logvar.contiguous().float()
         n_ws = lib.dvae_loss_ws_floats(C.byref(model._desc), C.byref(batch.counts))
         if n_ws < 0:
