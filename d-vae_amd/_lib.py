@@ -83,7 +83,8 @@ SIGNATURES = {
     "dvae_packed_floats": (C.c_int64, [_MD]),
     "dvae_pack_weights": (_I, [_MD, C.POINTER(_P), _P, _P]),
     "dvae_unpack_grads": (_I, [_MD, _P, _P, C.POINTER(_P), C.POINTER(C.c_uint8), _I, _P]),
-    "dvae_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _P]),
+    "dvae_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _I, _P]),
+    "dvae_repack_weights": (_I, [_MD, C.POINTER(_P), _P, _P]),
     "dvae_batch_create": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, C.POINTER(_P), _BC]),
     "dvae_batch_export": (_I, [_P, _P, C.c_int64]),
     "dvae_batch_destroy": (None, [_P]),

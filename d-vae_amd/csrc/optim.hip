@@ -10,9 +10,10 @@
 
 namespace dvae {
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4, float b1,
-                                                   float b2, float eps, float step_size, float inv_sqrt_bc2) {
+                                                   float b2, float eps, float step_size, float inv_sqrt_bc2,
+                                                   int zero_grad) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -28,13 +29,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = P;
         reinterpret_cast<float4*>(m)[i] = M;
         reinterpret_cast<float4*>(v)[i] = V;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // the next step's zero_grad
     }
 }
 
 }  // namespace dvae
 
-extern "C" int dvae_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                                  float beta2, float eps, int32_t step, void* stream) {
+extern "C" int dvae_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, int32_t step, int32_t zero_grad, void* stream) {
     using namespace dvae;
     if (n == 0) return DVAE_OK;
     DVAE_REQUIRE(p && g && m && v, "adam_step: null pointer");
@@ -49,7 +51,7 @@ extern "C" int dvae_adam_step_f32(float* p, const float* g, float* m, float* v, 
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, beta1,
-                       beta2, eps, step_size, inv_sqrt_bc2);
+                       beta2, eps, step_size, inv_sqrt_bc2, zero_grad != 0);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

@@ -8,29 +8,127 @@
 
 namespace dvae {
 
+// One launch moves everything: plain block copies AND the table builds / un-builds are entries of one op
+// table (a train step packs once and unpacks twice: 3 launches where there were 7 + 4 + 5).
+enum { OP_COPY = 0, OP_BUILD_GI, OP_BUILD_GV, OP_BUILD_BN, OP_UNBUILD_GI, OP_UNBUILD_GV, OP_UNBUILD_BN };
 struct CopyOp {
     const float* src;
     float* dst;
     int rows, cols, src_ld, dst_ld;
+    int kind;
+    // table ops (see the device functions below for each kind's meaning)
+    const float *a, *b;
+    float *d1, *d2;
+    int i0, i1, i2, i3, i4;
 };
-constexpr int MAX_OPS = 48;
+constexpr int MAX_OPS = 40;  // 40 x 88 bytes: inside the 4 KB kernel-argument segment
 struct CopyOps {
     CopyOp op[MAX_OPS];
     int n;
     int accumulate;  // dst += src
 };
 
+__device__ __forceinline__ void put(float* d, float v, int acc) { *d = acc ? *d + v : v; }
+
+// gi[t][q*Hp + j] = Wih[q*H + j][t] + bih[q*H + j] + (q < 2 ? bhh[q*H + j] : 0)
+//   src = wih, a = bih, b = bhh, dst = gi; i0 = T, i1 = H, i2 = Hp
+__device__ __forceinline__ void build_gi(const CopyOp& o, int i) {
+    const int T = o.i0, H = o.i1, Hp = o.i2;
+    if (i >= T * 3 * H) return;
+    int t = i / (3 * H), r = i % (3 * H), q = r / H, j = r % H;
+    o.dst[(long)t * 3 * Hp + q * Hp + j] = o.src[(long)r * T + t] + o.a[r] + (q < 2 ? o.b[r] : 0.f);
+}
+// the transpose: src = d gi, a = d bhn, dst = d wih, d1 = d bih, d2 = d bhh (each nullable)
+__device__ __forceinline__ void unbuild_gi(const CopyOp& o, int r, int acc) {
+    const int T = o.i0, H = o.i1, Hp = o.i2;
+    if (r >= 3 * H) return;
+    int q = r / H, j = r % H;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float v = o.src[(long)t * 3 * Hp + q * Hp + j];
+        if (o.dst) put(o.dst + (long)r * T + t, v, acc);
+        s += v;
+    }
+    if (o.d1) put(o.d1 + r, s, acc);
+    if (o.d2) put(o.d2 + r, q < 2 ? s : o.a[j], acc);
+}
+// gv[v][j] = (vid ? Wg[j][H+v] : 0) + bg[j];  gv[v][Hp+j] = vid ? Wm[j][H+v] : 0
+//   src = wg, a = bg, b = wm, dst = gv; i0 = n, i1 = H, i2 = Hp, i3 = V, i4 = vid
+__device__ __forceinline__ void build_gv(const CopyOp& o, int i) {
+    const int n = o.i0, H = o.i1, Hp = o.i2, V = o.i3, vid = o.i4;
+    if (i >= n * H) return;
+    int v = i / H, j = i % H;
+    o.dst[(long)v * 2 * Hp + j] = (vid ? o.src[(long)j * V + H + v] : 0.f) + o.a[j];
+    o.dst[(long)v * 2 * Hp + Hp + j] = vid ? o.b[(long)j * V + H + v] : 0.f;
+}
+// src = d gv, dst = d wg, d1 = d bg, d2 = d wm
+__device__ __forceinline__ void unbuild_gv(const CopyOp& o, int j, int acc) {
+    const int n = o.i0, H = o.i1, Hp = o.i2, V = o.i3, vid = o.i4;
+    if (j >= H) return;
+    float s = 0.f;
+    for (int v = 0; v < n; ++v) {
+        float a = o.src[(long)v * 2 * Hp + j];
+        s += a;
+        if (vid) {
+            if (o.dst) put(o.dst + (long)j * V + H + v, a, acc);
+            if (o.d2) put(o.d2 + (long)j * V + H + v, o.src[(long)v * 2 * Hp + Hp + j], acc);
+        }
+    }
+    if (o.d1) put(o.d1 + j, s, acc);
+}
+// BN message table: gated(u) = sigmoid(Wg[:, t_u] + bg) * Wm[:, t_u]  (models.py:1044-1062)
+//   src = wg, a = bg, b = wm, dst = gtab, d1 = gtg, d2 = gtm; i0 = T, i1 = H, i2 = Hp
+__device__ __forceinline__ void build_bn(const CopyOp& o, int i) {
+    const int T = o.i0, H = o.i1, Hp = o.i2;
+    if (i >= T * H) return;
+    int t = i / H, j = i % H;
+    float g = 1.f / (1.f + expf(-(o.src[(long)j * T + t] + o.a[j])));
+    float m = o.b[(long)j * T + t];
+    o.d1[(long)t * Hp + j] = g;
+    o.d2[(long)t * Hp + j] = m;
+    o.dst[(long)t * Hp + j] = g * m;
+}
+// src = d gtab, a = gtg, b = gtm, dst = d wg, d1 = d bg, d2 = d wm
+__device__ __forceinline__ void unbuild_bn(const CopyOp& o, int j, int acc) {
+    const int T = o.i0, H = o.i1, Hp = o.i2;
+    if (j >= H) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float d = o.src[(long)t * Hp + j], g = o.a[(long)t * Hp + j], m = o.b[(long)t * Hp + j];
+        float da = d * m * g * (1.f - g);
+        s += da;
+        if (o.dst) put(o.dst + (long)j * T + t, da, acc);
+        if (o.d2) put(o.d2 + (long)j * T + t, d * g, acc);
+    }
+    if (o.d1) put(o.d1 + j, s, acc);
+}
+
 // grid (COPY_WGS, ops): a workgroup walks whole rows of its op, its threads the columns of a row
 // (coalesced on both sides, no division per element; H = 501 leaves the source rows unaligned, so
-// the accesses stay one float wide)
+// the accesses stay one float wide); the table ops grid-stride over their (few) elements
 constexpr int COPY_WGS = 256;
 __global__ __launch_bounds__(256) void copy_ops_kernel(CopyOps ops) {
     const CopyOp& o = ops.op[blockIdx.y];
+    const int acc = ops.accumulate;
+    if (o.kind != OP_COPY) {  // (uniform over the workgroup)
+        const int total = o.rows;  // number of work items of the table op
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += COPY_WGS * 256) {
+            switch (o.kind) {
+            case OP_BUILD_GI: build_gi(o, i); break;
+            case OP_BUILD_GV: build_gv(o, i); break;
+            case OP_BUILD_BN: build_bn(o, i); break;
+            case OP_UNBUILD_GI: unbuild_gi(o, i, acc); break;
+            case OP_UNBUILD_GV: unbuild_gv(o, i, acc); break;
+            default: unbuild_bn(o, i, acc); break;
+            }
+        }
+        return;
+    }
     const int rows = o.rows, cols = o.cols;
     if (rows == 1) {  // a bias vector: spread its columns over the workgroups
         for (int c = blockIdx.x * 256 + threadIdx.x; c < cols; c += COPY_WGS * 256) {
             const float v = o.src[c];
-            o.dst[c] = ops.accumulate ? o.dst[c] + v : v;
+            o.dst[c] = acc ? o.dst[c] + v : v;
         }
         return;
     }
@@ -39,86 +137,9 @@ __global__ __launch_bounds__(256) void copy_ops_kernel(CopyOps ops) {
         float* dp = o.dst + (long)r * o.dst_ld;
         for (int c = threadIdx.x; c < cols; c += 256) {
             const float v = sp[c];
-            dp[c] = ops.accumulate ? dp[c] + v : v;
+            dp[c] = acc ? dp[c] + v : v;
         }
     }
-}
-
-// gi[t][q*Hp + j] = Wih[q*H + j][t] + bih[q*H + j] + (q < 2 ? bhh[q*H + j] : 0)
-__global__ void build_gi_kernel(float* gi, const float* wih, const float* bih, const float* bhh, int T, int H, int Hp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * 3 * H) return;
-    int t = i / (3 * H), r = i % (3 * H), q = r / H, j = r % H;
-    float v = wih[(long)r * T + t] + bih[r] + (q < 2 ? bhh[r] : 0.f);
-    gi[(long)t * 3 * Hp + q * Hp + j] = v;
-}
-__device__ __forceinline__ void put(float* d, float v, int acc) { *d = acc ? *d + v : v; }
-
-__global__ void unbuild_gi_kernel(const float* dgi, const float* dbhn, float* dwih, float* dbih, float* dbhh, int T,
-                                  int H, int Hp, int acc) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= 3 * H) return;
-    int q = r / H, j = r % H;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) {
-        float v = dgi[(long)t * 3 * Hp + q * Hp + j];
-        if (dwih) put(dwih + (long)r * T + t, v, acc);
-        s += v;
-    }
-    if (dbih) put(dbih + r, s, acc);
-    if (dbhh) put(dbhh + r, q < 2 ? s : dbhn[j], acc);
-}
-
-// gv[v][j] = (vid ? Wg[j][H+v] : 0) + bg[j];  gv[v][Hp+j] = vid ? Wm[j][H+v] : 0
-__global__ void build_gv_kernel(float* gv, const float* wg, const float* bg, const float* wm, int n, int H, int Hp,
-                                int V, int vid) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * H) return;
-    int v = i / H, j = i % H;
-    gv[(long)v * 2 * Hp + j] = (vid ? wg[(long)j * V + H + v] : 0.f) + bg[j];
-    gv[(long)v * 2 * Hp + Hp + j] = vid ? wm[(long)j * V + H + v] : 0.f;
-}
-__global__ void unbuild_gv_kernel(const float* dgv, float* dwg, float* dbg, float* dwm, int n, int H, int Hp, int V,
-                                  int vid, int acc) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= H) return;
-    float s = 0.f;
-    for (int v = 0; v < n; ++v) {
-        float a = dgv[(long)v * 2 * Hp + j];
-        s += a;
-        if (vid) {
-            if (dwg) put(dwg + (long)j * V + H + v, a, acc);
-            if (dwm) put(dwm + (long)j * V + H + v, dgv[(long)v * 2 * Hp + Hp + j], acc);
-        }
-    }
-    if (dbg) put(dbg + j, s, acc);
-}
-
-// BN message table: gated(u) = sigmoid(Wg[:, t_u] + bg) * Wm[:, t_u]  (models.py:1044-1062)
-__global__ void build_bn_table_kernel(float* gtab, float* gtg, float* gtm, const float* wg, const float* bg,
-                                      const float* wm, int T, int H, int Hp) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * H) return;
-    int t = i / H, j = i % H;
-    float g = 1.f / (1.f + expf(-(wg[(long)j * T + t] + bg[j])));
-    float m = wm[(long)j * T + t];
-    gtg[(long)t * Hp + j] = g;
-    gtm[(long)t * Hp + j] = m;
-    gtab[(long)t * Hp + j] = g * m;
-}
-__global__ void unbuild_bn_table_kernel(const float* dgtab, const float* gtg, const float* gtm, float* dwg, float* dbg,
-                                        float* dwm, int T, int H, int Hp, int acc) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= H) return;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) {
-        float d = dgtab[(long)t * Hp + j], g = gtg[(long)t * Hp + j], m = gtm[(long)t * Hp + j];
-        float da = d * m * g * (1.f - g);
-        s += da;
-        if (dwg) put(dwg + (long)j * T + t, da, acc);
-        if (dwm) put(dwm + (long)j * T + t, d * g, acc);
-    }
-    if (dbg) put(dbg + j, s, acc);
 }
 
 // native <-> packed block copies.  `nat[i]` may be null (absent parameter).
@@ -130,7 +151,7 @@ static int block_ops(const Dims& d, const PackedLayout& L, float* const* nat, fl
     const int H = d.H, Hp = d.Hp;
     auto add = [&](int pid, size_t nat_off, int nat_ld, size_t pk_off, int pk_ld, int rows, int cols) {
         if (!nat[pid] || (want && !want[pid])) return;
-        CopyOp o;
+        CopyOp o = {};
         if (to_packed) { o.src = nat[pid] + nat_off; o.dst = pk + pk_off; o.src_ld = nat_ld; o.dst_ld = pk_ld; }
         else { o.src = pk + pk_off; o.dst = nat[pid] + nat_off; o.src_ld = pk_ld; o.dst_ld = nat_ld; }
         o.rows = rows; o.cols = cols;
@@ -178,8 +199,15 @@ static int block_ops(const Dims& d, const PackedLayout& L, float* const* nat, fl
         add(P_HG_W, H, 2 * H, L.wu + Hp, 2 * Hp, H, H);
         add(P_HG_B, 0, H, L.bu, H, 1, H);
     }
-    if (ops.n > MAX_OPS) return set_err(DVAE_ERR_SIZE, "copy-op table overflow");
+    if (ops.n > MAX_OPS - 5) return set_err(DVAE_ERR_SIZE, "copy-op table overflow");  // (5 table ops may follow)
     return DVAE_OK;
+}
+static void table_op(CopyOps& ops, int kind, int items, const float* src, const float* a, const float* b, float* dst,
+                     float* d1, float* d2, int i0, int i1, int i2, int i3 = 0, int i4 = 0) {
+    CopyOp o = {};
+    o.kind = kind; o.rows = items; o.src = src; o.a = a; o.b = b; o.dst = dst; o.d1 = d1; o.d2 = d2;
+    o.i0 = i0; o.i1 = i1; o.i2 = i2; o.i3 = i3; o.i4 = i4;
+    ops.op[ops.n++] = o;
 }
 
 static int run_ops(const CopyOps& ops, hipStream_t s) {
@@ -211,37 +239,40 @@ extern "C" int64_t dvae_packed_floats(const dvae_model_desc* m) {
     return (int64_t)make_layout(d).total;
 }
 
-extern "C" int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream) {
+static int pack_impl(const dvae_model_desc* m, const float* const* params, float* packed, bool zero_first, void* stream) {
     Dims d;
     DVAE_TRY(make_dims(m, d));
     DVAE_REQUIRE(params && packed, "dvae_pack_weights: null pointer");
     DVAE_TRY(check_params(d, params));
     hipStream_t s = (hipStream_t)stream;
     PackedLayout L = make_layout(d);
-    DVAE_HIP(hipMemsetAsync(packed, 0, L.total * sizeof(float), s));
+    if (zero_first) DVAE_HIP(hipMemsetAsync(packed, 0, L.total * sizeof(float), s));
     CopyOps ops;
     DVAE_TRY(block_ops(d, L, const_cast<float* const*>(reinterpret_cast<const float* const*>(params)), packed, true, ops, nullptr));
-    DVAE_TRY(run_ops(ops, s));
     const int wih[3] = {P_EF_WIH, P_EB_WIH, P_D_WIH};
     for (int g = 0; g < 3; ++g) {
         if (!params[wih[g]]) continue;
-        hipLaunchKernelGGL(build_gi_kernel, dim3(cdiv(d.T * 3 * d.H, 256)), dim3(256), 0, s, packed + L.gi[g],
-                           params[wih[g]], params[wih[g] + 2], params[wih[g] + 3], d.T, d.H, d.Hp);
+        table_op(ops, OP_BUILD_GI, d.T * 3 * d.H, params[wih[g]], params[wih[g] + 2], params[wih[g] + 3], packed + L.gi[g],
+                 nullptr, nullptr, d.T, d.H, d.Hp);
     }
     const int gw[2] = {P_GF_W, P_GB_W}, gb[2] = {P_GF_B, P_GB_B}, mw[2] = {P_MF_W, P_MB_W};
     for (int k = 0; k < 2; ++k) {
         if (!params[gw[k]] || !params[gb[k]] || !params[mw[k]]) continue;
-        if (d.bn) {
-            hipLaunchKernelGGL(build_bn_table_kernel, dim3(cdiv(d.T * d.H, 256)), dim3(256), 0, s, packed + L.gtab[k],
-                               packed + L.gtg[k], packed + L.gtm[k], params[gw[k]], params[gb[k]], params[mw[k]], d.T,
-                               d.H, d.Hp);
-        } else {
-            hipLaunchKernelGGL(build_gv_kernel, dim3(cdiv(d.n * d.H, 256)), dim3(256), 0, s, packed + L.gv[k],
-                               params[gw[k]], params[gb[k]], params[mw[k]], d.n, d.H, d.Hp, d.V, d.vid);
-        }
+        if (d.bn)
+            table_op(ops, OP_BUILD_BN, d.T * d.H, params[gw[k]], params[gb[k]], params[mw[k]], packed + L.gtab[k],
+                     packed + L.gtg[k], packed + L.gtm[k], d.T, d.H, d.Hp);
+        else
+            table_op(ops, OP_BUILD_GV, d.n * d.H, params[gw[k]], params[gb[k]], params[mw[k]], packed + L.gv[k], nullptr,
+                     nullptr, d.n, d.H, d.Hp, d.V, d.vid);
     }
-    DVAE_LAUNCH_CHECK();
-    return DVAE_OK;
+    return run_ops(ops, s);
+}
+
+extern "C" int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream) {
+    return pack_impl(m, params, packed, true, stream);
+}
+extern "C" int dvae_repack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream) {
+    return pack_impl(m, params, packed, false, stream);
 }
 
 // packed gradient buffer -> native gradient tensors.  `want[i]` != 0 selects the
@@ -259,15 +290,12 @@ extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w
     CopyOps ops;
     DVAE_TRY(block_ops(d, L, grads, const_cast<float*>(packed_g), false, ops, w));
     ops.accumulate = accumulate != 0;
-    const int acc = accumulate != 0;
-    DVAE_TRY(run_ops(ops, s));
     const int wih[3] = {P_EF_WIH, P_EB_WIH, P_D_WIH};
     for (int g = 0; g < 3; ++g) {
         int a = wih[g];
         if (!(w[a] || w[a + 2] || w[a + 3])) continue;
-        hipLaunchKernelGGL(unbuild_gi_kernel, dim3(cdiv(3 * d.H, 256)), dim3(256), 0, s, packed_g + L.gi[g],
-                           packed_g + L.bhn[g], w[a] ? grads[a] : nullptr, w[a + 2] ? grads[a + 2] : nullptr,
-                           w[a + 3] ? grads[a + 3] : nullptr, d.T, d.H, d.Hp, acc);
+        table_op(ops, OP_UNBUILD_GI, 3 * d.H, packed_g + L.gi[g], packed_g + L.bhn[g], nullptr, w[a] ? grads[a] : nullptr,
+                 w[a + 2] ? grads[a + 2] : nullptr, w[a + 3] ? grads[a + 3] : nullptr, d.T, d.H, d.Hp);
     }
     const int gw[2] = {P_GF_W, P_GB_W}, gb[2] = {P_GF_B, P_GB_B}, mw[2] = {P_MF_W, P_MB_W};
     for (int k = 0; k < 2; ++k) {
@@ -277,13 +305,11 @@ extern "C" int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w
         float* dwm = w[mw[k]] ? grads[mw[k]] : nullptr;
         if (d.bn) {
             DVAE_REQUIRE(packed_w != nullptr, "dvae_unpack_grads: BN needs the packed weights (gate tables)");
-            hipLaunchKernelGGL(unbuild_bn_table_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gtab[k],
-                               packed_w + L.gtg[k], packed_w + L.gtm[k], dwg, dbg, dwm, d.T, d.H, d.Hp, acc);
+            table_op(ops, OP_UNBUILD_BN, d.H, packed_g + L.gtab[k], packed_w + L.gtg[k], packed_w + L.gtm[k], dwg, dbg, dwm,
+                     d.T, d.H, d.Hp);
         } else {
-            hipLaunchKernelGGL(unbuild_gv_kernel, dim3(cdiv(d.H, 256)), dim3(256), 0, s, packed_g + L.gv[k], dwg, dbg,
-                               dwm, d.n, d.H, d.Hp, d.V, d.vid, acc);
+            table_op(ops, OP_UNBUILD_GV, d.H, packed_g + L.gv[k], nullptr, nullptr, dwg, dbg, dwm, d.n, d.H, d.Hp, d.V, d.vid);
         }
     }
-    DVAE_LAUNCH_CHECK();
-    return DVAE_OK;
+    return run_ops(ops, s);
 }

@@ -53,6 +53,10 @@ class GradSumReducer(object):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
         self._early = None
         self.extra_params = []
+        # True while the flat buffer is known to hold zeros (FlatAdam's kernel leaves it zeroed after a step and the
+        # model clears the flag before it adds gradients): zero() is then free.  Code that writes into the .grad views
+        # by hand between an optimizer step and zero() would have those writes wiped by zero() anyway.
+        self.clean = False
         # backward() then adds straight into these views (no autograd accumulation kernels)
         if sink and hasattr(model, "attach_grad_sink") and self.flat.is_cuda:
             model.attach_grad_sink(True, self)
@@ -107,6 +111,8 @@ class GradSumReducer(object):
         if self._early is not None:  # a step was abandoned between backward() and all_reduce()
             self._early.wait()
             self._early = None
+        if self.clean and self.flat.is_cuda:
+            return
         self.flat.zero_()
 
     def all_reduce(self):

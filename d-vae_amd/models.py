@@ -87,6 +87,9 @@ class _EncodeFn(torch.autograd.Function):
     def backward(ctx, dmu, dlogvar):
         lib = _lib.load()
         model, batch = ctx.model, ctx.batch
+        if ctx.ws is None:
+            raise RuntimeError("encode(): backward through the graph a second time (the workspace of the forward pass "
+                               "is released by the first backward; retain_graph is not supported)")
         dev = ctx.ws.device
         dmu = torch.zeros(batch.B, model.nz, device=dev) if dmu is None else dmu.contiguous().float()
         dlogvar = torch.zeros(batch.B, model.nz, device=dev) if dlogvar is None else dlogvar.contiguous().float()
@@ -95,6 +98,7 @@ class _EncodeFn(torch.autograd.Function):
                                             ctx.pw.data_ptr(), ctx.ws.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(),
                                             pg.data_ptr(), _stream()), "dvae_encode_backward")
         grads = model._unpack(ctx.pw, pg, model._enc_names)
+        ctx.ws = ctx.pw = None  # release the workspace and the packed weights (which can then be re-packed in place)
         return (None, None) + tuple(grads)
 
 
@@ -124,6 +128,9 @@ class _LossFn(torch.autograd.Function):
         lib = _lib.load()
         model, batch = ctx.model, ctx.batch
         mu_c, lv_c, eps, eps_scale, training, beta = ctx.args
+        if ctx.ws is None:
+            raise RuntimeError("loss(): backward through the graph a second time (the workspace of the forward pass "
+                               "is released by the first backward; retain_graph is not supported)")
         dev = ctx.ws.device
         g3 = g3.contiguous().float()
         pg = torch.empty(model._n_packed, dtype=torch.float32, device=dev)
@@ -135,6 +142,7 @@ class _LossFn(torch.autograd.Function):
                                           g3.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(), pg.data_ptr(), _stream()),
                    "dvae_loss_backward")
         grads = model._unpack(ctx.pw, pg, model._dec_names)
+        ctx.ws = ctx.pw = None
         if model._grad_sink and getattr(model, "_reducer", None) is not None:
             model._reducer.decoder_grads_ready()
         return (None, None, None, None, None, None, dmu, dlogvar) + tuple(grads)
@@ -196,6 +204,7 @@ class DVAE(nn.Module):
         self._n_packed = None
         self._pw = None
         self._pw_key = None
+        self._pw_dirty = False
         self._named_cache = None
         self._grad_sink = getattr(self, "_grad_sink", False)
         self._reducer = getattr(self, "_reducer", None)
@@ -224,14 +233,17 @@ class DVAE(nn.Module):
         return [named[k] for k in names]
 
     def _packed_weights(self):
-        """Zero-padded device copy of the weights, rebuilt when any parameter
-        changed (optimizer steps bump tensor versions)."""
+        """Zero-padded device copy of the weights, rebuilt when any parameter changed (optimizer steps bump
+        tensor versions; FlatAdam, which writes through raw pointers, sets `_pw_dirty`).  The buffer is kept
+        and re-packed in place (one launch, padding stays zero) unless a live autograd graph still holds it
+        for its backward pass: then a fresh one is built."""
+        import sys
         lib = _lib.load()
         table = self._param_table()
         first = next(p for p in table if p is not None)
         _require_gpu(first, "DVAE")
         key = tuple((p.data_ptr(), p._version) if p is not None else None for p in table)
-        if self._pw is not None and key == self._pw_key and self._pw.device == first.device:
+        if self._pw is not None and key == self._pw_key and not self._pw_dirty and self._pw.device == first.device:
             return self._pw
         if self._n_packed is None:
             self._n_packed = int(lib.dvae_packed_floats(C.byref(self._desc)))
@@ -241,10 +253,18 @@ class DVAE(nn.Module):
             if p is not None and (p.dtype != torch.float32 or not p.is_contiguous()):
                 raise _lib.DvaeHipError("parameters must be contiguous float32")
         arr = (C.c_void_p * _lib.NUM_PARAMS)(*[p.data_ptr() if p is not None else None for p in table])
-        pw = torch.empty(self._n_packed, dtype=torch.float32, device=first.device)
-        _lib.check(lib.dvae_pack_weights(C.byref(self._desc), arr, pw.data_ptr(), _stream()), "dvae_pack_weights")
-        self._pw, self._pw_key = pw, key
-        return pw
+        # same set of parameters as the buffer was packed from (absent ones leave zeros), and nobody else holds it
+        # (references: the attribute and getrefcount's argument)
+        reuse = (self._pw is not None and self._pw.device == first.device and self._pw_key is not None and
+                 [k is None for k in key] == [k is None for k in self._pw_key] and sys.getrefcount(self._pw) <= 2)
+        if reuse:
+            _lib.check(lib.dvae_repack_weights(C.byref(self._desc), arr, self._pw.data_ptr(), _stream()), "dvae_repack_weights")
+        else:
+            pw = torch.empty(self._n_packed, dtype=torch.float32, device=first.device)
+            _lib.check(lib.dvae_pack_weights(C.byref(self._desc), arr, pw.data_ptr(), _stream()), "dvae_pack_weights")
+            self._pw = pw
+        self._pw_key, self._pw_dirty = key, False
+        return self._pw
 
     def _unpack(self, pw, pg, names):
         """Packed gradient buffer -> gradients of `names`.  Default: fresh tensors, returned to
@@ -268,6 +288,8 @@ class DVAE(nn.Module):
                 grads.append(g)
             ptrs[_IDX[k]] = g.data_ptr()
             want[_IDX[k]] = 1
+        if sink and self._reducer is not None:
+            self._reducer.clean = False  # the flat gradient buffer is about to be added to
         arr = (C.c_void_p * _lib.NUM_PARAMS)(*ptrs)
         w = (C.c_uint8 * _lib.NUM_PARAMS)(*want)
         _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), arr, w, int(bool(sink)),

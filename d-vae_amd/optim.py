@@ -37,7 +37,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(r.flat)
         self.exp_avg_sq = torch.zeros_like(r.flat)
         self.steps = 0
-        model._pw = None  # parameter storage moved: repack
+        model._pw = None  # parameter storage moved: pack afresh
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero()
@@ -58,12 +58,17 @@ class FlatAdam(torch.optim.Optimizer):
                                         "was built?); build the optimizer after the last .to()")
         self.steps += 1
         lib = _lib.load()
+        # zero_grad: with the gradient sink attached every write to the flat gradient buffer goes through the model
+        # (which clears `reducer.clean`), so the kernel can leave the buffer zeroed and the next zero_grad() is free
+        zero = int(bool(getattr(self.model, "_grad_sink", False)) and getattr(self.model, "_reducer", None) is r)
         _lib.check(lib.dvae_adam_step_f32(self.flat_p.data_ptr(), self.reducer.flat.data_ptr(), self.exp_avg.data_ptr(),
                                           self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]),
-                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps,
+                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, zero,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dvae_adam_step_f32")
-        # the kernel wrote through raw pointers: tensor versions did not move, so drop the packed copy
-        self.model._pw = None
+        if zero:
+            r.clean = True
+        # the kernel wrote through raw pointers: tensor versions did not move, so the packed copy is stale
+        self.model._pw_dirty = True
         if self.extra is not None:
             for eg in self.extra.param_groups:
                 eg["lr"] = g["lr"]  # follows a scheduler attached to this optimizer

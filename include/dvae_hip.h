@@ -274,6 +274,9 @@ typedef struct dvae_model_desc {
 int64_t dvae_packed_floats(const dvae_model_desc* m);
 /* native parameters -> packed buffer (call after every optimizer step) */
 int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream);
+/* the same into a buffer that already holds a pack of this model (its zero padding is intact): only the
+ * live entries are rewritten, in one launch */
+int dvae_repack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream);
 /* packed gradient buffer -> native gradient tensors; want[i] != 0 selects which
  * of grads[0..DVAE_NUM_PARAMS) are written: fully overwritten, or, with accumulate != 0, added to
  * in place (PyTorch's .grad accumulation without a temporary). */
@@ -282,9 +285,10 @@ int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const flo
 
 /* One Adam step over a flat fp32 buffer of n floats (n % 4 == 0; parameters, gradients and the
  * two moments laid out alike): torch.optim.Adam's update as the reference configures it
- * (train.py:174; no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
-int dvae_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, int32_t step, void* stream);
+ * (train.py:174; no weight decay, no amsgrad).  `step` counts from 1 (bias correction).  zero_grad != 0: the
+ * gradient buffer is left at zero (the optimizer.zero_grad() of the next step, train.py:225, in the same pass). */
+int dvae_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t step, int32_t zero_grad, void* stream);
 
 /* ---------------------------------------------------------------------------
  * DAG batching (host).  Replaces models.py:631-632 (_collate_fn), the per-vertex
