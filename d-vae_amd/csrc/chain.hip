@@ -68,6 +68,11 @@ template <int V>
 struct IC { static constexpr int value = V; };  // compile-time register-set index for the staging lambdas
 // (The K loop has NO branch between its steps: with conditional loads hipcc's wait-count insertion
 // falls back to s_waitcnt vmcnt(0) before every LDS store, which drains all the tiles in flight.)
+// Diagnostic builds only (tools/chain_ablate.sh; results are wrong, only the time matters): CHAIN_ABL bit 0 drops the
+// pointwise tail (the K-slice exchange stays), bit 1 the MFMAs, bit 2 runs one K step instead of all.
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0
+#endif
 #ifndef CHAIN_PF
 #define CHAIN_PF 2  // register-staged tiles in flight in the unrolled kernels (1, 2, 4 or 8; measured: no effect beyond 1)
 #endif
@@ -225,6 +230,10 @@ __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&ac
             v[i] = s;
         }
         const int col = n0 + 8 * q + 4 * h;
+        if (CHAIN_ABL & 1) {  // keep the sums alive, touch no tail operand
+            if (v[0].x == 123.456f) p.C[0] = v[NGATE - 1].y;
+            continue;
+        }
         if (TAIL == 0) {
             gru_tail(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
         } else if (TAIL == 1) {
@@ -394,27 +403,32 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
                 }
             }
         }
+#if CHAIN_ABL & 2
+#define CHAIN_MFMA(a_, b_, c_) ({ f32x16 r_ = (c_); r_[0] += (a_) * (b_); r_; })
+#else
+#define CHAIN_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+#endif
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].x, fa[gg].x, acc[D][i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = CHAIN_MFMA(fw[gg][i].x, fa[gg].x, acc[D][i]);
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].y, fa[gg].y, acc[D][i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = CHAIN_MFMA(fw[gg][i].y, fa[gg].y, acc[D][i]);
             if (gg == 0) {
                 // step s+1 (in flight for PF steps): registers -> the other stage; reload from step s+1+PF
                 lstore(IC<J + 1>{}, ns, s + 1);
                 gload(IC<J + 1 + PF>{}, s + 1 + PF);
             }
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].z, fa[gg].z, acc[D][i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = CHAIN_MFMA(fw[gg][i].z, fa[gg].z, acc[D][i]);
 #pragma unroll
-            for (int i = 0; i < NGATE; ++i) acc[D][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[gg][i].w, fa[gg].w, acc[D][i], 0, 0, 0);
+            for (int i = 0; i < NGATE; ++i) acc[D][i] = CHAIN_MFMA(fw[gg][i].w, fa[gg].w, acc[D][i]);
         }
         __syncthreads();  // stage s^1 complete; every wave holds its fragments of stage s in registers
     };
     if constexpr (NK > 0) {
 #pragma unroll
-        for (int s = 0; s < NK * ND; s += U) chain_steps<0, U>(step, s);  // s % U == 0: sets and levels are constants
+        for (int s = 0; s < ((CHAIN_ABL & 4) ? U : NK * ND); s += U) chain_steps<0, U>(step, s);  // s % U == 0: sets and levels are constants
     } else {
         for (int s = 0; s < ns_total; s += U) chain_steps<0, U>(step, s);
     }

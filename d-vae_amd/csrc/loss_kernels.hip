@@ -214,8 +214,14 @@ __global__ void vertex_ce_kernel(const float* __restrict__ logits, int ld, const
 // zero-padded [B][NZp] buffer; kld = -0.5 sum(1 + logvar - mu^2 - exp(logvar)) (:859)
 __global__ void reparam_kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                                        const float* __restrict__ eps, float eps_scale, int training,
-                                       float* __restrict__ z, float* __restrict__ kld_sum, int B, int nz, int NZp) {
+                                       float* __restrict__ z, float* __restrict__ kld_sum, int B, int nz, int NZp,
+                                       float* __restrict__ zero_a, float* __restrict__ zero_b, int HEp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_a)  // the all-zero rows of the two edge-predictor tables (two memsets otherwise)
+        for (int c = i; c < HEp; c += gridDim.x * blockDim.x) {
+            zero_a[c] = 0.f;
+            zero_b[c] = 0.f;
+        }
     float local = 0.f;
     if (i < B * NZp) {
         int b = i / NZp, j = i % NZp;
@@ -255,6 +261,133 @@ __global__ void reparam_kld_bwd_kernel(const float* __restrict__ mu, const float
     if (training) dv += d * eps[i] * eps_scale * 0.5f * expf(0.5f * lv);
     dmu[i] = dm;
     dlogvar[i] = dv;
+}
+
+// ---------------------------------------------------------------------------
+// Small batches / latent sizes: the head of loss() as ONE single-workgroup launch -- reparameterisation + KLD (no
+// atomics: the workgroup owns the sum), the zeroing of the loss accumulators `sums[0..7]` and of the two all-zero
+// rows of the edge-predictor tables (three memsets otherwise).
+__global__ __launch_bounds__(1024) void loss_fwd_init_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                            const float* __restrict__ eps, float eps_scale, int training,
+                                                            float* __restrict__ z, float* __restrict__ sums,
+                                                            float* __restrict__ zero_a, float* __restrict__ zero_b,
+                                                            int HEp, int B, int nz, int NZp) {
+    float local = 0.f;
+    for (int i = threadIdx.x; i < B * NZp; i += 1024) {
+        int b = i / NZp, j = i % NZp;
+        float zv = 0.f;
+        if (j < nz) {
+            float m = mu[b * nz + j], lv = logvar[b * nz + j];
+            zv = m;
+            if (training) zv = eps[b * nz + j] * eps_scale * expf(0.5f * lv) + m;
+            local += -0.5f * (1.f + lv - m * m - expf(lv));
+        }
+        z[i] = zv;
+    }
+    for (int c = threadIdx.x; c < HEp; c += 1024) {
+        zero_a[c] = 0.f;
+        zero_b[c] = 0.f;
+    }
+    local = wave_sum(local);
+    __shared__ float red[16];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = local;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float v = 0.f;
+        if (threadIdx.x == 2)
+            for (int w = 0; w < 16; ++w) v += red[w];
+        sums[threadIdx.x] = v;  // {pair loss, CE loss, kld, -, arrival counter of vertex_ce_final, -, -, -}
+    }
+}
+
+// vertex-type CE whose LAST workgroup to finish also writes the three outputs of loss()
+// (out3 = {res + beta kld, res, kld}): the separate finalize launch is gone.  sums[4] is the arrival counter
+// (zeroed with the other accumulators); sums are read back with atomics, which execute at the memory side.
+__global__ void vertex_ce_final_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ ce_off,
+                                       const int* __restrict__ ce_tgt, float* __restrict__ dlogits,
+                                       float* __restrict__ sums, float beta, float* __restrict__ out3, int R, int T,
+                                       int Tp) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float local = 0.f;
+    if (r < R) {
+        const float* x = logits + (long)r * ld;
+        float mx = -INFINITY;
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, x[t]);
+        float se = 0.f;
+        for (int t = 0; t < T; ++t) se += expf(x[t] - mx);
+        float lse = mx + logf(se);
+        int k0 = ce_off[r], k1 = ce_off[r + 1];
+        float cnt = (float)(k1 - k0);
+        float* d = dlogits + (long)r * Tp;
+        for (int t = 0; t < Tp; ++t) d[t] = t < T ? cnt * expf(x[t] - lse) : 0.f;
+        for (int k = k0; k < k1; ++k) {
+            int tg = ce_tgt[k];
+            local += lse - x[tg];
+            d[tg] -= 1.f;
+        }
+    }
+    local = wave_sum(local);
+    __shared__ float red[4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = red[0] + red[1] + red[2] + red[3];
+        if (v != 0.f) atomicAdd(sums + 1, v);
+        __threadfence();
+        unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(sums + 4), 1u);
+        if (ticket == gridDim.x - 1) {
+            __threadfence();
+            float pair = atomicAdd(sums + 0, 0.f), ce = atomicAdd(sums + 1, 0.f), kld = atomicAdd(sums + 2, 0.f);
+            float res = pair + ce;
+            out3[0] = res + beta * kld;
+            out3[1] = res;
+            out3[2] = kld;
+        }
+    }
+}
+
+// Head of loss backward as ONE launch (was: grad_scales, scaled_copy and two whole-table memsets):
+//   gs = {d/d res, d/d kld} from the upstream gradients g3 of (loss, res, kld)
+//   dlogits_s = dlogits * gs[0]
+//   rows of the two edge-predictor gradient tables that pair_bwd_kernel ADDS into (rows with several chunks: bit 31
+//   of chunk_row) and their last, all-zero-input row are zeroed; every other row is written whole by its one chunk
+__global__ __launch_bounds__(256) void loss_bwd_init_kernel(const float* __restrict__ g3, float beta, float* __restrict__ gs,
+                                                            const float* __restrict__ dlogits, float* __restrict__ dlogits_s,
+                                                            long n_logits, int blocks_copy, const int* __restrict__ ca_row,
+                                                            int CA, float* __restrict__ dea, int NA, int blocks_a,
+                                                            const int* __restrict__ ch_row, int CH, float* __restrict__ deb,
+                                                            int NB, int HEp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int blk = blockIdx.x;
+    if (blk < blocks_copy) {
+        const float g0 = g3[0] + g3[1];
+        if (blk == 0 && threadIdx.x == 0) {
+            gs[0] = g0;
+            gs[1] = beta * g3[0] + g3[2];
+        }
+        for (long i = blk * 256L + threadIdx.x; i < n_logits; i += blocks_copy * 256L) dlogits_s[i] = dlogits[i] * g0;
+        return;
+    }
+    blk -= blocks_copy;
+    const int* rowv = ch_row;
+    float* tab = deb;
+    int nch = CH, last = NB;
+    if (blk < blocks_a) { rowv = ca_row; tab = dea; nch = CA; last = NA; }
+    else blk -= blocks_a;
+    // one wave per chunk; chunk nch stands for the table's last row
+    const int q = blk * 4 + wave;
+    if (q > nch) return;
+    int row = last;
+    if (q < nch) {
+        const int cr = rowv[q];
+        if (cr >= 0) return;  // single-chunk row: written whole by its chunk
+        row = cr & 0x7fffffff;
+        if (q > 0 && (rowv[q - 1] & 0x7fffffff) == row) return;  // not the row's first chunk
+    }
+    float* d = tab + (long)row * HEp;
+    for (int c = lane * 4; c < HEp; c += 256) *reinterpret_cast<float4*>(d + c) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace dvae
@@ -339,6 +472,33 @@ extern "C" int dvae_vertex_ce(const float* logits, int32_t ld, const int32_t* ce
 }
 
 namespace dvae {
+int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
+                  float* sums, float* zero_row_a, float* zero_row_b, int HEp, int B, int nz, int NZp, hipStream_t s) {
+    hipLaunchKernelGGL(loss_fwd_init_kernel, dim3(1), dim3(1024), 0, s, mu, logvar, eps, eps_scale, training, z, sums,
+                       zero_row_a, zero_row_b, HEp, B, nz, NZp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* ce_tgt, float* dlogits, float* sums,
+                    float beta, float* out3, int R, int T, int Tp, hipStream_t s) {
+    DVAE_REQUIRE(R > 0 && T > 0 && T <= Tp && ld >= T, "vertex_ce: bad R/T/Tp/ld");
+    hipLaunchKernelGGL(vertex_ce_final_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, logits, ld, ce_off, ce_tgt, dlogits,
+                       sums, beta, out3, R, T, Tp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+int loss_bwd_init(const float* g3, float beta, float* gs, const float* dlogits, float* dlogits_s, long n_logits,
+                  const int* ca_row, int CA, float* dea, int NA, const int* ch_row, int CH, float* deb, int NB, int HEp,
+                  hipStream_t s) {
+    int blocks_copy = cdiv(n_logits, 256 * 4);
+    if (blocks_copy < 1) blocks_copy = 1;
+    if (blocks_copy > 512) blocks_copy = 512;
+    const int blocks_a = cdiv(CA + 1, 4), blocks_b = cdiv(CH + 1, 4);
+    hipLaunchKernelGGL(loss_bwd_init_kernel, dim3(blocks_copy + blocks_a + blocks_b), dim3(256), 0, s, g3, beta, gs, dlogits,
+                       dlogits_s, n_logits, blocks_copy, ca_row, CA, dea, NA, blocks_a, ch_row, CH, deb, NB, HEp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
 int scale_inplace(float* x, const float* s, int n, hipStream_t st) {
     if (n <= 0) return DVAE_OK;
     hipLaunchKernelGGL(scale_inplace_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, s, n);
@@ -346,9 +506,9 @@ int scale_inplace(float* x, const float* s, int n, hipStream_t st) {
     return DVAE_OK;
 }
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
-                    float* kld_sum, int B, int nz, int NZp, hipStream_t s) {
+                    float* kld_sum, int B, int nz, int NZp, hipStream_t s, float* zero_a, float* zero_b, int HEp) {
     hipLaunchKernelGGL(reparam_kld_fwd_kernel, dim3(cdiv((long)B * NZp, 256)), dim3(256), 0, s, mu, logvar, eps,
-                       eps_scale, training, z, kld_sum, B, nz, NZp);
+                       eps_scale, training, z, kld_sum, B, nz, NZp, zero_a, zero_b, HEp);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

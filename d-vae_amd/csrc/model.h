@@ -86,8 +86,18 @@ static inline PackedLayout make_layout(const Dims& d) {
 int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split = 0);  // max_split > 0 caps the split-K factor
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);
 int scale_inplace(float* x, const float* s, int n, hipStream_t st);
+int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
+                    float* ghn_out, int rows, int Hp, hipStream_t s);
+int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
+                  float* sums, float* zero_row_a, float* zero_row_b, int HEp, int B, int nz, int NZp, hipStream_t s);
+int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* ce_tgt, float* dlogits, float* sums,
+                    float beta, float* out3, int R, int T, int Tp, hipStream_t s);
+int loss_bwd_init(const float* g3, float beta, float* gs, const float* dlogits, float* dlogits_s, long n_logits,
+                  const int* ca_row, int CA, float* dea, int NA, const int* ch_row, int CH, float* deb, int NB, int HEp,
+                  hipStream_t s);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
-                    float* kld_sum, int B, int nz, int NZp, hipStream_t s);
+                    float* kld_sum, int B, int nz, int NZp, hipStream_t s, float* zero_a = nullptr, float* zero_b = nullptr,
+                    int HEp = 0);
 int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training,
                     const float* dz, const float* gk, float* dmu, float* dlogvar, int B, int nz, int NZp, hipStream_t s);
 

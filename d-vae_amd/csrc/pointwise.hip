@@ -80,6 +80,42 @@ __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__
     }
 }
 
+// The first level of an encoder pass: no predecessors, so h_prev = 0 and the hidden product is 0 (models.py:682 with
+// H = zeros).  Same arithmetic as gru_fwd_kernel on a zero gh / zero h_prev, without reading either; also leaves the
+// zeros the backward pass expects in the level's agg rows (its h_prev) -- one launch instead of two memsets + one.
+__global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __restrict__ gi_tab,
+                                     const int* __restrict__ types, const float* __restrict__ bhn,
+                                     float* __restrict__ agg_zero, float* __restrict__ hout, float* __restrict__ ghn_out,
+                                     int rows, int Hp) {
+    int w4 = Hp / 4;
+    long total = (long)rows * w4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i / w4), c = (int)(i % w4) * 4;
+        float* g = gates + (long)r * 3 * Hp;
+        const float* gi = gi_tab + (long)types[r] * 3 * Hp;
+        float4 gir = ld4(gi + c), giz = ld4(gi + Hp + c), gin = ld4(gi + 2 * Hp + c);
+        float4 bn = ld4(bhn + c);
+        float4 R, Z, N, Hn;
+#define GRU0(f)                                          \
+    {                                                    \
+        float gn = 0.f + bn.f;                           \
+        float rr = 1.f / (1.f + expf(-(gir.f + 0.f)));   \
+        float zz = 1.f / (1.f + expf(-(giz.f + 0.f)));   \
+        float nn = tanhf(gin.f + rr * gn);               \
+        R.f = rr; Z.f = zz; N.f = nn;                    \
+        Hn.f = (1.f - zz) * nn + zz * 0.f;               \
+    }
+        GRU0(x) GRU0(y) GRU0(z) GRU0(w)
+#undef GRU0
+        st4(g + c, R);
+        st4(g + Hp + c, Z);
+        st4(g + 2 * Hp + c, N);
+        st4(ghn_out + (long)r * Hp + c, bn);
+        st4(hout + (long)r * Hp + c, Hn);
+        st4(agg_zero + (long)r * Hp + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
 __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const float* __restrict__ gates,
                                const float* __restrict__ ghn, const float* __restrict__ hprev, int ld_hprev,
                                float* __restrict__ dgh, float* __restrict__ dgin, float* __restrict__ dhprev,
@@ -372,6 +408,18 @@ extern "C" int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int3
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
+
+namespace dvae {
+int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
+                    float* ghn_out, int rows, int Hp, hipStream_t s) {
+    if (rows == 0) return DVAE_OK;
+    long total = (long)rows * (Hp / 4);
+    hipLaunchKernelGGL(gru_fwd_first_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gates, gi_tab, types, bhn, agg_zero,
+                       hout, ghn_out, rows, Hp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+}  // namespace dvae
 
 extern "C" int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const float* gates, const float* ghn,
                                       const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,

@@ -437,16 +437,16 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         const long r0 = (long)v * B;
         float* agg = w.agg[k] + r0 * Hp;
         float* gates = w.gates[k] + r0 * 3 * Hp;
-        if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0
-            DVAE_HIP(hipMemsetAsync(agg, 0, sizeof(float) * (size_t)B * Hp, s));
-            DVAE_HIP(hipMemsetAsync(gates, 0, sizeof(float) * (size_t)B * 3 * Hp, s));
+        if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0 (one launch; leaves agg = 0 for the backward)
+            DVAE_TRY(gru_first_level(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, w.hs[k] + r0 * Hp,
+                                     w.ghn[k] + r0 * Hp, B, Hp, s));
         } else if (!fused) {
             DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
         }
         if (fused && step > 0)  // hidden product + GRU tail in one launch (chain.hip)
             DVAE_TRY(dvae_gru_level_fwd(agg, Hp, pw + L.whh[k], pw + L.gi[k], bv.types + r0, pw + L.bhn[k], gates,
                                         w.ghn[k] + r0 * Hp, w.hs[k] + r0 * Hp, Hp, B, Hp, s));
-        else
+        else if (step > 0)
             DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp,
                                             w.hs[k] + r0 * Hp, Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
         if (step < n - 1) {
@@ -748,8 +748,18 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     Side* side = nullptr;
     SideGuard side_guard{side, s};
     if (by_level) DVAE_TRY(side_for_stream(s, &side));
-    DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
-    DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s));
+    // small batches (launch-bound): one single-workgroup launch does the accumulators' and the tables' zero rows'
+    // zeroing too; larger ones keep the multi-workgroup kernel (a lone workgroup walking 64 k elements was measured
+    // 0.4 % slower on the cfg-2 step than the launches it saved), which still zeroes the two rows
+    const bool one_init = (long)B * d.NZp <= 8192;
+    if (one_init) {
+        DVAE_TRY(loss_fwd_init(mu, logvar, eps, eps_scale, training, w.z, w.sums, w.ea + (size_t)c->NA * HEp,
+                               w.eb + (size_t)c->NB * HEp, HEp, B, d.nz, d.NZp, s));
+    } else {
+        DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
+        DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s,
+                                 w.ea + (size_t)c->NA * HEp, w.eb + (size_t)c->NB * HEp, HEp));
+    }
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
     const bool fused = chain_fused(d, c->B);
@@ -816,8 +826,6 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // edge predictor: first layer split over its inputs
     if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
     DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s));
-    DVAE_HIP(hipMemsetAsync(w.ea + (size_t)c->NA * HEp, 0, sizeof(float) * HEp, s));
-    DVAE_HIP(hipMemsetAsync(w.eb + (size_t)c->NB * HEp, 0, sizeof(float) * HEp, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
     if (by_level) DVAE_TRY(join_side(side, s));
     DVAE_TRY(dvae_pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t,
@@ -830,9 +838,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     }
     // (the Tp-wide logits product stays one launch: a level's slice of it is 16 workgroups)
     DVAE_TRY(lin_fwd(w.v1, d.HVp, nullptr, pw + L.wv2, d.HVp, pw + L.bv2, w.logits, d.Tp, c->R, d.Tp, d.HVp, 0, 0, s));
-    DVAE_TRY(dvae_vertex_ce(w.logits, d.Tp, bv.ce_off, bv.ce_tgt, w.dlogits, w.sums + 1, c->R, d.T, d.Tp, s));
-    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, s, w.sums, beta, out3);
-    DVAE_LAUNCH_CHECK();
+    // (the last workgroup of the CE kernel writes out3 = {res + beta kld, res, kld})
+    DVAE_TRY(vertex_ce_final(w.logits, d.Tp, bv.ce_off, bv.ce_tgt, w.dlogits, w.sums, beta, out3, c->R, d.T, d.Tp, s));
     return DVAE_OK;
 }
 
@@ -854,13 +861,14 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     const bool fused = chain_fused_bwd(d, c->B);
 
     DVAE_HIP(hipMemsetAsync(pg, 0, L.total * sizeof(float), s));
-    hipLaunchKernelGGL(grad_scales_kernel, dim3(1), dim3(1), 0, s, g3, beta, w.gs);
     const float* g_res = w.gs;
     const float* g_kld = w.gs + 1;
+    // one launch: gs from g3, dlogits_s = dlogits * gs[0], and the rows of the two edge-predictor gradient tables that
+    // the grouped passes below ADD into are zeroed (all other rows are written whole by their one chunk)
+    DVAE_TRY(loss_bwd_init(g3, beta, w.gs, w.dlogits, w.dlogits_s, (long)c->R * d.Tp, bv.ca_row, c->CA, w.dea, c->NA,
+                           bv.ch_row, c->CH, w.deb, c->NB, HEp, s));
 
     // ---- edge predictor ------------------------------------------------------------
-    DVAE_HIP(hipMemsetAsync(w.dea, 0, sizeof(float) * (size_t)(c->NA + 1) * HEp, s));
-    DVAE_HIP(hipMemsetAsync(w.deb, 0, sizeof(float) * (size_t)(c->NB + 1) * HEp, s));
     // the forward left the ReLU masks: each pass is one sweep over (dl, mask) and writes its table
     DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.ca_off, bv.ca_row, bv.ca_pairs, w.dl, w.mask, pw + L.we2, g_res, w.dea,
                                        c->CA, HEp, s));
@@ -878,7 +886,6 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(side_for_stream(s, &side));
     DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
     // vertex-type predictor, data path (main stream)
-    EW(scaled_copy_kernel, (long)c->R * d.Tp, w.dlogits_s, w.dlogits, g_res, (long)c->R * d.Tp);
     // (the ReLU backward of add_vertex's hidden layer is the product's epilogue: masked by v1 > 0)
     DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s, w.v1));
     DVAE_TRY(fork_side(side, s));
