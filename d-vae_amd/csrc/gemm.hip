@@ -212,9 +212,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // at once; each walks its tiles, so a tile's stores drain under the next tile's prologue
     // instead of holding the workgroup's slot until they are acknowledged.
     const int ntiles = p.tiles_x * p.tiles_y;
+    // The first K tile of a workgroup's NEXT output tile is requested BEFORE the current tile's epilogue: vector
+    // memory operations complete in issue order, so loads issued behind the epilogue's 64 stores per lane would
+    // wait for all of them; issued ahead, they land while the stores drain and the next tile starts at once.
+    LA la; LB lb;
+    int m0 = 0, n0 = 0;
+    auto tile = [&](int t) { int k = kbeg + t * BK; return k < kend ? k : kbeg; };  // clamped past the end (loaded, never used)
+    auto begin_tile = [&](int tl) {
+        tile_origin<BM, BN>(tl, p.tiles_x, ntiles, m0, n0);
+        la.init(p.A, p.a_rows, p.lda, m0, p.M, tid);
+        lb.init(p.B, p.b_rows, p.ldb, n0, p.N, tid);
+        lb.next_idx(tile(0), kend, tid);
+        la.load(tile(0), kend, tid);
+        lb.load(tile(0), kend, tid);
+        lb.next_idx(tile(1), kend, tid);
+    };
+    if ((int)blockIdx.x < ntiles) begin_tile(blockIdx.x);
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-    int m0, n0;
-    tile_origin<BM, BN>(tl, p.tiles_x, ntiles, m0, n0);
+    const int cm0 = m0, cn0 = n0;  // this tile's origin (begin_tile for the next one moves m0 / n0)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -224,15 +239,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    LA la; LB lb;
-    la.init(p.A, p.a_rows, p.lda, m0, p.M, tid);
-    lb.init(p.B, p.b_rows, p.ldb, n0, p.N, tid);
-    // tile(t) = kbeg + t*BK, clamped to a valid tile past the end (loaded, never used)
-    auto tile = [&](int t) { int k = kbeg + t * BK; return k < kend ? k : kbeg; };
-    lb.next_idx(tile(0), kend, tid);
-    la.load(tile(0), kend, tid);
-    lb.load(tile(0), kend, tid);
-    lb.next_idx(tile(1), kend, tid);
     la.store(lds, tid);
     lb.store(lds + LA::LDS_ELEMS, tid);
     la.load(tile(1), kend, tid);
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    store_acc<TM, TN, SWAP>(p, acc, m0, n0, wm, wn, lane, BM, BN);
+    if (tl + (int)gridDim.x < ntiles) begin_tile(tl + gridDim.x);
+    store_acc<TM, TN, SWAP>(p, acc, cm0, cn0, wm, wn, lane, BM, BN);
     }  // tiles
 }
 

@@ -12,6 +12,23 @@ namespace dvae {
 
 __device__ __forceinline__ float4 ld4c(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// The loss terms are summed into sums[0..2] = {pair BCE, vertex CE, KLD} by kernels that may run on two streams; each
+// of their workgroups, after its own atomic add, draws a ticket from sums[4], and the one that draws the last of
+// `total` tickets writes out3 = {res + beta kld, res, kld} (models.py:858-860): no separate finalize launch, and no
+// order between the kernels.  Called by ONE thread per workgroup; sums are read back with atomics (memory side).
+__device__ __forceinline__ void loss_ticket(float* sums, unsigned total, float beta, float* out3) {
+    __threadfence();
+    const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(sums + 4), 1u);
+    if (ticket == total - 1) {
+        __threadfence();
+        const float pair = atomicAdd(sums + 0, 0.f), ce = atomicAdd(sums + 1, 0.f), kld = atomicAdd(sums + 2, 0.f);
+        const float res = pair + ce;
+        out3[0] = res + beta * kld;
+        out3[1] = res;
+        out3[2] = kld;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Edge predictor tail + BCE.  A wave owns a pair; lane l holds the 4 hidden units
 // c = 4 l + 256 i + {0..3} of iteration i (coalesced float4 rows).  NIT = number of
@@ -30,7 +47,8 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ dl, float* __restrict__ loss_sum,
                                                        uint32_t* __restrict__ mask, float* __restrict__ dw2_partial,
-                                                       int n_pairs, int HEp) {
+                                                       int n_pairs, int HEp, float* __restrict__ sums,
+                                                       unsigned tickets, float beta, float* __restrict__ out3) {
     constexpr int NW = (NIT + 7) / 8;
     extern __shared__ float sh[];  // [HEp] workgroup sum of the w2-gradient partials (+ 4 floats)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
     if (threadIdx.x == 0) {
         float v = red[0] + red[1] + red[2] + red[3];
         if (v != 0.f) atomicAdd(loss_sum, v);
+        if (sums) loss_ticket(sums, tickets, beta, out3);
     }
     if (dw2_partial) {  // uniform
 #pragma unroll
@@ -306,8 +325,8 @@ __global__ __launch_bounds__(1024) void loss_fwd_init_kernel(const float* __rest
 // (zeroed with the other accumulators); sums are read back with atomics, which execute at the memory side.
 __global__ void vertex_ce_final_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ ce_off,
                                        const int* __restrict__ ce_tgt, float* __restrict__ dlogits,
-                                       float* __restrict__ sums, float beta, float* __restrict__ out3, int R, int T,
-                                       int Tp) {
+                                       float* __restrict__ sums, unsigned tickets, float beta,
+                                       float* __restrict__ out3, int R, int T, int Tp) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     float local = 0.f;
     if (r < R) {
@@ -335,16 +354,7 @@ __global__ void vertex_ce_final_kernel(const float* __restrict__ logits, int ld,
     if (threadIdx.x == 0) {
         float v = red[0] + red[1] + red[2] + red[3];
         if (v != 0.f) atomicAdd(sums + 1, v);
-        __threadfence();
-        unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(sums + 4), 1u);
-        if (ticket == gridDim.x - 1) {
-            __threadfence();
-            float pair = atomicAdd(sums + 0, 0.f), ce = atomicAdd(sums + 1, 0.f), kld = atomicAdd(sums + 2, 0.f);
-            float res = pair + ce;
-            out3[0] = res + beta * kld;
-            out3[1] = res;
-            out3[2] = kld;
-        }
+        loss_ticket(sums, tickets, beta, out3);
     }
 }
 
@@ -405,22 +415,23 @@ extern "C" int64_t dvae_pair_mask_words(int32_t n_pairs, int32_t HEp) {
     return (int64_t)n_pairs * ((nit + 7) / 8) * 64;
 }
 
-extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a,
-                                 const int32_t* pair_h, const int32_t* pair_c, const uint8_t* pair_t, const float* b1,
-                                 const float* w2, const float* b2, float* dl, float* loss_sum, uint32_t* mask,
-                                 float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp, void* stream) {
+namespace dvae {
+int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a, const int32_t* pair_h,
+                 const int32_t* pair_c, const uint8_t* pair_t, const float* b1, const float* w2, const float* b2, float* dl,
+                 float* loss_sum, uint32_t* mask, float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp,
+                 float* sums, unsigned tickets, float beta, float* out3, void* stream) {
     DVAE_REQUIRE(ea && eb && pair_a && pair_h && pair_t && b1 && w2 && b2 && dl && loss_sum, "pair_bce_fwd: null pointer");
     DVAE_REQUIRE((ec == nullptr) == (pair_c == nullptr), "pair_bce_fwd: ec and pair_c go together");
     DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0 && n_blocks > 0, "pair_bce_fwd: HEp must be a multiple of 4, n_blocks > 0");
     const int nit = pair_nit(HEp);
     DVAE_REQUIRE(nit > 0, "pair_bce_fwd: HEp %d exceeds 4096", HEp);
-    if (n_pairs == 0 && !dw2_partial) return DVAE_OK;
+    if (n_pairs == 0 && !dw2_partial && !sums) return DVAE_OK;
     const size_t shm = ((size_t)HEp + 4) * sizeof(float);
     dim3 grid(n_blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define DVAE_PAIR_FWD(N)                                                                                              \
     hipLaunchKernelGGL((pair_fwd_kernel<N>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, \
-                       b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp)
+                       b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3)
     switch (nit) {
         case 1: DVAE_PAIR_FWD(1); break;
         case 2: DVAE_PAIR_FWD(2); break;
@@ -431,6 +442,15 @@ extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* 
 #undef DVAE_PAIR_FWD
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+
+extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a,
+                                 const int32_t* pair_h, const int32_t* pair_c, const uint8_t* pair_t, const float* b1,
+                                 const float* w2, const float* b2, float* dl, float* loss_sum, uint32_t* mask,
+                                 float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp, void* stream) {
+    return dvae::pair_bce_fwd(ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, b2, dl, loss_sum, mask, dw2_partial, n_blocks,
+                              n_pairs, HEp, nullptr, 0u, 0.f, nullptr, stream);
 }
 
 extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,
@@ -479,11 +499,12 @@ int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float 
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
+int vertex_ce_blocks(int R) { return cdiv(R, 256); }
 int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* ce_tgt, float* dlogits, float* sums,
-                    float beta, float* out3, int R, int T, int Tp, hipStream_t s) {
+                    unsigned tickets, float beta, float* out3, int R, int T, int Tp, hipStream_t s) {
     DVAE_REQUIRE(R > 0 && T > 0 && T <= Tp && ld >= T, "vertex_ce: bad R/T/Tp/ld");
-    hipLaunchKernelGGL(vertex_ce_final_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, logits, ld, ce_off, ce_tgt, dlogits,
-                       sums, beta, out3, R, T, Tp);
+    hipLaunchKernelGGL(vertex_ce_final_kernel, dim3(vertex_ce_blocks(R)), dim3(256), 0, s, logits, ld, ce_off, ce_tgt, dlogits,
+                       sums, tickets, beta, out3, R, T, Tp);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

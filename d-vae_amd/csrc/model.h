@@ -90,8 +90,13 @@ int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, con
                     float* ghn_out, int rows, int Hp, hipStream_t s);
 int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                   float* sums, float* zero_row_a, float* zero_row_b, int HEp, int B, int nz, int NZp, hipStream_t s);
+int vertex_ce_blocks(int R);
 int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* ce_tgt, float* dlogits, float* sums,
-                    float beta, float* out3, int R, int T, int Tp, hipStream_t s);
+                    unsigned tickets, float beta, float* out3, int R, int T, int Tp, hipStream_t s);
+int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a, const int32_t* pair_h,
+                 const int32_t* pair_c, const uint8_t* pair_t, const float* b1, const float* w2, const float* b2, float* dl,
+                 float* loss_sum, uint32_t* mask, float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp,
+                 float* sums, unsigned tickets, float beta, float* out3, void* stream);
 int loss_bwd_init(const float* g3, float beta, float* gs, const float* dlogits, float* dlogits_s, long n_logits,
                   const int* ca_row, int CA, float* dea, int NA, const int* ch_row, int CH, float* deb, int NB, int HEp,
                   hipStream_t s);
