@@ -390,6 +390,10 @@ static bool chain_fused_bwd(const Dims& d, int B) {
 // delay the level kernels they share CUs with), so the default is the decoder only.  Capping the terms' split-K at 1
 // (fewer workgroups, no atomics) and a low-priority side stream were measured too: 4.16 ms and no change.
 // DVAE_WGRAD_BY_LEVEL: bit 0 decoder, bit 1 encoder (default 1; 0 = whole-pass products after the chains).
+static int pair_group_knob() {
+    static const int knob = [] { const char* v = getenv("DVAE_PAIR_GROUP"); return v ? atoi(v) : 1; }();
+    return knob;
+}
 static int wbl_knob() {
     static const int knob = [] { const char* v = getenv("DVAE_WGRAD_BY_LEVEL"); return v ? atoi(v) : 1; }();
     return knob;
@@ -840,7 +844,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     if (by_level) DVAE_TRY(join_side(side, s));
     DVAE_TRY(pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t, pw + L.be1,
                           pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, w.dw2_blocks, c->NP, HEp, w.sums, tickets,
-                          beta, out3, s));
+                          beta, out3, s, pair_group_knob() ? c->NP / c->B : 0));
     // vertex-type predictor
     if (!by_level) {
         DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
