@@ -28,6 +28,7 @@
 // backward products [64 k][40] read with ds_read_b32; two stages, register-staged global loads,
 // one barrier per K step.
 #include "gemm_common.h"
+#include "model.h"
 
 namespace dvae {
 
@@ -64,6 +65,21 @@ struct ChainParams {
 
 __device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void cst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Write-through (sc1) 16-byte accesses for data that ANOTHER workgroup of the same launch reads or wrote (the
+// persistent chain kernel below): the store leaves L2 at once, the load bypasses this CU's L1, so the hand-off needs
+// no release / acquire fence (cdna_hip_programming.md guideline 16, form R1).  aux 16 = sc1.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFF0u, 0x00020000);
+}
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
+}
 template <int V>
 struct IC { static constexpr int value = V; };  // compile-time register-set index for the staging lambdas
 // (The K loop has NO branch between its steps: with conditional loads hipcc's wait-count insertion
@@ -82,11 +98,13 @@ struct IC { static constexpr int value = V; };  // compile-time register-set ind
 // was measured: no change per kernel, and the extra live registers (GRU forward 146 -> 202) keep the
 // side stream's kernels off the CUs the chain occupies: loss forward 0.86 -> 0.97 ms.  Not done.)
 // GRUCell tail for 4 consecutive hidden units of one row (same arithmetic as gru_fwd_kernel)
+template <bool SC1>
 __device__ __forceinline__ void gru_tail(const ChainParams& p, int row, int col, float4 ghr, float4 ghz, float4 ghn) {
     const float* gi = p.gi_tab + (long)p.types[row] * 3 * p.Hp;
     const float4 gir = cld4(gi + col), giz = cld4(gi + p.Hp + col), gin = cld4(gi + 2 * p.Hp + col);
     const float4 bn = cld4(p.bhn + col);
-    const float4 hp = cld4(p.hprev + (long)row * p.ld_hprev + col);
+    const float4 hp = SC1 ? ld4_sc1(rsrc_of(p.hprev), (unsigned)((row * p.ld_hprev + col) * 4))
+                          : cld4(p.hprev + (long)row * p.ld_hprev + col);
     float4 R, Z, N, Hn, GN;
 #define GRU1(f)                                          \
     {                                                    \
@@ -104,11 +122,13 @@ __device__ __forceinline__ void gru_tail(const ChainParams& p, int row, int col,
     cst4(g + p.Hp + col, Z);
     cst4(g + 2 * p.Hp + col, N);
     cst4(p.ghn + (long)row * p.Hp + col, GN);
-    cst4(p.hout + (long)row * p.ld_hout + col, Hn);
+    if (SC1) st4_sc1(rsrc_of(p.hout), (unsigned)((row * p.ld_hout + col) * 4), Hn);  // read by the row tile's other workgroups
+    else cst4(p.hout + (long)row * p.ld_hout + col, Hn);
 }
 
 // gate/mapper tail + the next level's predecessor sum (same arithmetic and summation order as
 // gated_fwd_gather_kernel)
+template <bool SC1>
 __device__ __forceinline__ void gate_tail(const ChainParams& p, int row, int col, float4 pg, float4 pm) {
     const float4 vg = cld4(p.gv + col), vm = cld4(p.gv + p.Hp + col);
     const float4 a = make_float4(pg.x + vg.x, pg.y + vg.y, pg.z + vg.z, pg.w + vg.w);
@@ -127,7 +147,8 @@ __device__ __forceinline__ void gate_tail(const ChainParams& p, int row, int col
             const float4 v = s == p.cur_row0 + row ? own : cld4(p.msg + (long)s * p.ld_msg + col);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        cst4(p.next_agg + (long)row * p.ld_agg + col, acc);
+        if (SC1) st4_sc1(rsrc_of(p.next_agg), (unsigned)((row * p.ld_agg + col) * 4), acc);
+        else cst4(p.next_agg + (long)row * p.ld_agg + col, acc);
     }
 }
 
@@ -192,7 +213,7 @@ __device__ __forceinline__ void gather_bwd_tail(const ChainParams& p, int row, i
 // The wave of K slice KQ finishes 4 / KS register quads (quad q = columns 8 q + 4 (lane / 32) .. + 3):
 // it hands the other quads to their owners through LDS, adds the partial sums it receives and
 // its own IN K ORDER, and runs the tail.
-template <int NGATE, int TAIL, int KS, int KQ>
+template <int NGATE, int TAIL, int KS, int KQ, bool SC1>
 __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&acc)[NGATE], float* lds, int m0, int n0,
                                                int wm, int lane) {
     constexpr int QPW = 4 / KS;  // register quads a wave finishes: quads KQ * QPW .. + QPW - 1
@@ -235,9 +256,9 @@ __device__ __forceinline__ void chain_epilogue(const ChainParams& p, f32x16 (&ac
             continue;
         }
         if (TAIL == 0) {
-            gru_tail(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
+            gru_tail<SC1>(p, row, col, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
         } else if (TAIL == 1) {
-            gate_tail(p, row, col, v[0], v[NGATE - 1]);
+            gate_tail<SC1>(p, row, col, v[0], v[NGATE - 1]);
         } else {
             float* c = p.C + (long)row * p.ldc + col;
             const float4 c0 = cld4(c);
@@ -284,8 +305,21 @@ __device__ __forceinline__ void chain_prefetch(F& gload) {
     }
 }
 
-template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK, int ND>
-__global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
+template <int NGATE, bool WKM, int KS>
+struct ChainLds {
+    static constexpr int CBK = 16 * KS;
+    static constexpr int CLD = CBK + 4;
+    static constexpr int A_ELEMS = CBM * CLD;
+    static constexpr int W_ELEMS = WKM ? CBK * CLW : NGATE * 32 * CLD;
+    static constexpr int STAGE = A_ELEMS + W_ELEMS;
+    static constexpr int FLOATS = 2 * STAGE;
+};
+
+// One level operation of one output tile (workgroup `bid` of tiles_x * tiles_y): the body of chain_kernel, also
+// called phase by phase by the persistent kernel below (SC1: the A operand and the tail's hand-off arrays are
+// accessed write-through, see ld4_sc1).  `lds` holds ChainLds<NGATE, WKM, KS>::FLOATS floats.
+template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK, int ND, bool SC1>
+__device__ __forceinline__ void chain_body(const ChainBatch& batch, float* lds, int bid) {
     const ChainParams& p = batch.d[0];  // shape (M, Hp, K, tiles) is common to the levels of a launch
     constexpr int CBK = 16 * KS;   // K step: KS slices of 16, one per wave pair
     constexpr int CLD = CBK + 4;   // LDS row stride of a K-contiguous image (floats): ds_read_b128 conflict-free for 36 and 68
@@ -295,16 +329,17 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
     constexpr int STAGE = A_ELEMS + W_ELEMS;
     constexpr int WU = WKM ? 1 : NGATE;  // weight staging units (16 bytes) per thread; the A operand has 2
     constexpr int U = (PF % ND == 0) ? PF : PF * ND;  // lcm(PF, ND) for ND in {1, 2}
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    static_assert(!SC1 || ND == 1, "the write-through form runs one level per call");
     static_assert(KS == 2 || KS == 4, "two or four K slices");
     static_assert(ND == 1 || ND == 2, "one or two levels per workgroup");
     static_assert(2 * STAGE * 4 >= 4 * (KS - 1) * 2 * NGATE * 64 * 16, "the K-slice exchange reuses the stage buffers");
+    static_assert(ChainLds<NGATE, WKM, KS>::FLOATS == 2 * STAGE, "LDS size");
     static_assert((NK * ND) % U == 0 && (NK > 0 || PF == 1), "the unroll group must divide the step count");
     static_assert(!WKM || NGATE == 1, "backward products have one output block per wave");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 1, wm = wave & 1;
     int m0, n0;
-    tile_origin<CBM, CBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
+    tile_origin<CBM, CBH>(bid, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
 
     // A: thread -> rows tid/C4R and tid/C4R + 32, 16 bytes at k (tid%C4R)*4
     // W K-contiguous: rows tid/C4R of each gate block, the same k;  W K-major: k row tid/8, columns (tid%8)*4
@@ -328,6 +363,18 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
             pw1[d] = pw2[d] = pw0[d];
         }
     }
+    // SC1: the A operand (states written by other workgroups of this launch) is read through a buffer descriptor with
+    // the sc1 bit; the byte offsets of the thread's two rows replace the row pointers
+    const __amdgpu_buffer_rsrc_t rsa = rsrc_of(batch.d[0].A);
+    unsigned oa0 = 0, oa1 = 0;
+    if (SC1) {
+        int r = m0 + ar;
+        r = r < p.M ? r : p.M - 1;
+        oa0 = (unsigned)(r * p.lda * 4);
+        r = m0 + ar + 32;
+        r = r < p.M ? r : p.M - 1;
+        oa1 = (unsigned)(r * p.lda * 4);
+    }
     const int sa = ar * CLD + ak;
     const int sw = A_ELEMS + (WKM ? (tid >> 3) * CLW + (tid & 7) * 4 : ar * CLD + ak);
     const int nk = NK > 0 ? NK : (p.K + CBK - 1) / CBK;
@@ -342,8 +389,13 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
         const int k0 = tile_of(s) * CBK;
         int ka = k0 + ak;
         ka = ka < p.K ? ka : ka - 32;
-        rs[s_][0] = cld4(pa0[d_] + ka);
-        rs[s_][1] = cld4(pa1[d_] + ka);
+        if (SC1) {
+            rs[s_][0] = ld4_sc1(rsa, oa0 + (unsigned)ka * 4u);
+            rs[s_][1] = ld4_sc1(rsa, oa1 + (unsigned)ka * 4u);
+        } else {
+            rs[s_][0] = cld4(pa0[d_] + ka);
+            rs[s_][1] = cld4(pa1[d_] + ka);
+        }
         if (!WKM) {
             rs[s_][2] = cld4(pw0[d_] + ka);
             if (NGATE > 1) rs[s_][WU > 1 ? 3 : 2] = cld4(pw1[d_] + ka);
@@ -437,13 +489,157 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
     for (int d = 0; d < ND; ++d) {
         if (d > 0) __syncthreads();  // the exchange buffer is reused
         const ChainParams& q = batch.d[d];
-        if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0>(q, acc[d], lds, m0, n0, wm, lane);
-        else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1>(q, acc[d], lds, m0, n0, wm, lane);
+        if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0, SC1>(q, acc[d], lds, m0, n0, wm, lane);
+        else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1, SC1>(q, acc[d], lds, m0, n0, wm, lane);
         else if constexpr (KS == 4) {
-            if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2>(q, acc[d], lds, m0, n0, wm, lane);
-            else chain_epilogue<NGATE, TAIL, KS, 3>(q, acc[d], lds, m0, n0, wm, lane);
+            if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2, SC1>(q, acc[d], lds, m0, n0, wm, lane);
+            else chain_epilogue<NGATE, TAIL, KS, 3, SC1>(q, acc[d], lds, m0, n0, wm, lane);
         }
     }
+}
+
+template <int NGATE, bool WKM, int TAIL, int KS, int PF, int NK, int ND>
+__global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
+    __shared__ __attribute__((aligned(16))) float lds[ChainLds<NGATE, WKM, KS>::FLOATS];
+    chain_body<NGATE, WKM, TAIL, KS, PF, NK, ND, false>(batch, lds, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------- persistent encoder chain
+// The whole forward chain of the encoder (models.py:675-685, both directions) as ONE launch.
+//
+// Graphs are independent, and level == vertex index keeps a graph in the same 64-row tile at every level; so a level
+// needs no grid barrier: the only workgroups that exchange data are the tiles_x (16) column tiles of one row tile --
+// the GRU product contracts over ALL hidden units of the previous level's sums `agg`, the gate/mapper product over all
+// of `hs`, each written 32 columns at a time by those workgroups.  Per (direction, row tile) one monotonic counter:
+// a workgroup adds 1 after each phase (GRU level, gate level, GRU level, ...), and waits for tiles_x * p before its
+// phase p.  Hand-off form (cdna_hip_programming.md guideline 16, R1 / MI355X_MICROARCH.md visibility table, first row):
+// payload stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane's
+// agent-scope atomic add; consumer: one lane polls the counter with sc1 loads, workgroup barrier, then sc1 loads only.
+// With two directions a workgroup alternates between them phase by phase, so the other direction's phase (10-15 us)
+// lies between a signal and the wait that needs it: the hand-off latency is hidden, and no launch boundary, cold
+// prologue burst or drain is paid per level.
+// All tiles_x * tiles_y workgroups must be co-resident (512 threads, 87 KB of LDS: one per CU, so at most 256); every
+// spin is bounded: on a timeout the workgroup raises status[0] and leaves, the others follow, and the host entry point's
+// caller finds the flag (results are then invalid).  Never run two of these launches at once on one device.
+// MEASURED (cfg 2, B = 1024, Hp = 512, 30 phases; profiles/r02_chain_ablation.txt): encoder forward 0.583 ms with this
+// launch vs 0.578-0.600 ms with the 30 level launches on two streams; whole step 3.981 vs 3.965 ms.  No gain: a phase is
+// 10.4 us of MFMA issue at 95 % of the fp32 matrix peak (the ablation below) + 3.9 us of tail, and the launch boundary
+// this kernel removes was already hidden by the other direction's kernel on the second stream.  Starting the odd row
+// tiles 1 / 2 / 3 us late (so that tails of one half fall into K loops of the other) changed nothing either.
+// Kept behind DVAE_CHAIN_PERSIST=1 (default off), parity-tested in tests/test_gpu_chain_modes.py.
+
+__device__ __forceinline__ bool chain_wait(unsigned* cnt, unsigned target, unsigned* status) {
+    // ONE lane polls (relaxed, agent scope = sc1 load); bounded
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            // ~1 us per poll: gives up after a few seconds, or within 64 polls of another workgroup giving up
+            if (++spins > (1u << 22) ||
+                ((spins & 63) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    return __syncthreads_and(ok ? 1 : 0) != 0;  // the barrier between the poll and every load of the handed-off data
+}
+__device__ __forceinline__ void chain_signal(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NK>
+__global__ __launch_bounds__(512) void enc_chain_fwd_kernel(EncChainArgs a) {
+    using LG = ChainLds<3, false, 4>;
+    __shared__ __attribute__((aligned(16))) float lds[LG::FLOATS];
+    constexpr int PF = NK > 0 ? CHAIN_PF : 1;
+    const int B = a.B, Hp = a.Hp, n = a.n;
+    const int tiles_x = Hp / CBH, tiles_y = (B + CBM - 1) / CBM;
+    int m0, n0;
+    tile_origin<CBM, CBH>(blockIdx.x, tiles_x, tiles_x * tiles_y, m0, n0);
+    const int rt = m0 / CBM;
+    ChainBatch cb;
+    ChainParams& p = cb.d[0];
+    for (int step = 0; step < n; ++step) {
+        // ---- GRU level of both directions
+        for (int d = 0; d < a.ndirs; ++d) {
+            const EncChainDir& e = a.d[d];
+            unsigned* cnt = a.sync + ((size_t)d * tiles_y + rt) * 32;
+            const int v = d == 0 ? step : n - 1 - step;
+            const long r0 = (long)v * B;
+            if (step == 0) {
+                // no predecessors: h_prev = 0, no product (gru_fwd_first_kernel's arithmetic) for this tile
+                const int row = m0 + (threadIdx.x >> 3), col = n0 + (threadIdx.x & 7) * 4;
+                if (row < B) {
+                    const float* gi = e.gi + (long)a.types[r0 + row] * 3 * Hp;
+                    const float4 gir = cld4(gi + col), giz = cld4(gi + Hp + col), gin = cld4(gi + 2 * Hp + col);
+                    const float4 bn = cld4(e.bhn + col);
+                    float4 R, Z, N, Hn;
+#define GRU0(f)                                          \
+    {                                                    \
+        float gn = 0.f + bn.f;                           \
+        float rr = 1.f / (1.f + expf(-(gir.f + 0.f)));   \
+        float zz = 1.f / (1.f + expf(-(giz.f + 0.f)));   \
+        float nn = tanhf(gin.f + rr * gn);               \
+        R.f = rr; Z.f = zz; N.f = nn;                    \
+        Hn.f = (1.f - zz) * nn + zz * 0.f;               \
+    }
+                    GRU0(x) GRU0(y) GRU0(z) GRU0(w)
+#undef GRU0
+                    float* g = e.gates + (r0 + row) * 3 * Hp;
+                    cst4(g + col, R);
+                    cst4(g + Hp + col, Z);
+                    cst4(g + 2 * Hp + col, N);
+                    cst4(e.ghn + (r0 + row) * Hp + col, bn);
+                    cst4(e.agg + (r0 + row) * Hp + col, make_float4(0.f, 0.f, 0.f, 0.f));
+                    st4_sc1(rsrc_of(e.hs + r0 * Hp), (unsigned)((row * Hp + col) * 4), Hn);
+                }
+            } else {
+                if (!chain_wait(cnt, (unsigned)(tiles_x * (2 * step)), a.status)) return;
+                p = ChainParams{};
+                p.A = e.agg + r0 * Hp; p.lda = Hp; p.W = e.whh; p.ldw = Hp; p.M = B; p.Hp = Hp; p.K = Hp;
+                p.tiles_x = tiles_x; p.tiles_y = tiles_y;
+                p.gi_tab = e.gi; p.types = a.types + r0; p.bhn = e.bhn; p.hprev = p.A; p.ld_hprev = Hp;
+                p.gates = e.gates + r0 * 3 * Hp; p.ghn = e.ghn + r0 * Hp; p.hout = e.hs + r0 * Hp; p.ld_hout = Hp;
+                chain_body<3, false, 0, 4, PF, NK, 1, true>(cb, lds, blockIdx.x);
+            }
+            chain_signal(cnt);
+        }
+        if (step == n - 1) break;  // the pass's last vertex sends no message
+        // ---- gate / mapper level of both directions (+ the next level's predecessor sums)
+        for (int d = 0; d < a.ndirs; ++d) {
+            const EncChainDir& e = a.d[d];
+            unsigned* cnt = a.sync + ((size_t)d * tiles_y + rt) * 32;
+            const int v = d == 0 ? step : n - 1 - step;
+            const long r0 = (long)v * B, r1 = (long)(d == 0 ? v + 1 : v - 1) * B;
+            if (!chain_wait(cnt, (unsigned)(tiles_x * (2 * step + 1)), a.status)) return;
+            p = ChainParams{};
+            p.A = e.hs + r0 * Hp; p.lda = Hp; p.W = e.wgm; p.ldw = Hp; p.M = B; p.Hp = Hp; p.K = Hp;
+            p.tiles_x = tiles_x; p.tiles_y = tiles_y;
+            p.gv = e.gv + (size_t)v * 2 * Hp; p.gm = e.gm + r0 * 2 * Hp; p.msg = e.msg; p.ld_msg = Hp; p.cur_row0 = (int)r0;
+            p.next_agg = e.agg + r1 * Hp; p.ld_agg = Hp; p.next_off = e.off + r1; p.idx = e.idx;
+            chain_body<2, false, 1, 4, PF, NK, 1, true>(cb, lds, blockIdx.x);
+            chain_signal(cnt);
+        }
+    }
+}
+
+int enc_chain_fwd(const EncChainArgs& a, hipStream_t s) {
+    const int tiles = (a.Hp / CBH) * cdiv(a.B, CBM);
+    DVAE_REQUIRE(a.ndirs >= 1 && a.ndirs <= 2 && a.Hp % 32 == 0 && tiles >= 1 && tiles <= 256,
+                 "persistent chain: needs Hp %% 32 == 0 and at most 256 tiles (one workgroup per CU); got Hp %d, %d tiles", a.Hp, tiles);
+    DVAE_REQUIRE((long)a.n * a.B * a.Hp * 4 < 4294967000L, "persistent chain: a state array exceeds 4 GiB");
+    DVAE_REQUIRE(a.status == a.sync + ENC_CHAIN_SYNC_WORDS - 64, "persistent chain: the status word follows the counters");
+    DVAE_HIP(hipMemsetAsync(a.sync, 0, sizeof(unsigned) * ENC_CHAIN_SYNC_WORDS, s));  // counters + status
+    const dim3 grid(tiles), block(512);
+    if (a.Hp == 512) hipLaunchKernelGGL((enc_chain_fwd_kernel<8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((enc_chain_fwd_kernel<0>), grid, block, 0, s, a);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
 }
 
 // ---------------------------------------------------------------------------------- host

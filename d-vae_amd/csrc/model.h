@@ -106,4 +106,20 @@ int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, floa
 int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training,
                     const float* dz, const float* gk, float* dmu, float* dlogvar, int B, int nz, int NZp, hipStream_t s);
 
+// chain.hip: the encoder's forward chain as one persistent launch (DVAE_CHAIN_PERSIST=1)
+constexpr int ENC_CHAIN_SYNC_WORDS = 2 * 256 * 32 + 64;  // [2 directions][<= 256 row tiles][32] counters, then the status word
+struct EncChainDir {
+    float *agg, *gates, *ghn, *hs, *gm, *msg;
+    const float *whh, *wgm, *gi, *bhn, *gv;
+    const int *off, *idx;  // CSR of the level's sources: predecessors (forward pass) / successors (backward pass)
+};
+struct EncChainArgs {
+    EncChainDir d[2];
+    const int* types;
+    int B, Hp, n, ndirs;
+    unsigned* sync;   // [ndirs][tiles_y][32] counters (128 bytes apart), zeroed before the launch
+    unsigned* status; // [1], zeroed before the launch; != 0: a wait timed out
+};
+int enc_chain_fwd(const EncChainArgs& a, hipStream_t s);
+
 }  // namespace dvae

@@ -27,12 +27,14 @@ __global__ void count_kernel(float* cnt, const int* off, const int* idx, int row
     cnt[i] = (float)c;
 }
 // out12 [B][2NZp] -> mu, logvar [B][nz]
-__global__ void split_mu_logvar_kernel(const float* out12, float* mu, float* logvar, int B, int nz, int NZp) {
+__global__ void split_mu_logvar_kernel(const float* out12, float* mu, float* logvar, int B, int nz, int NZp,
+                                       const unsigned* failed) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * nz) return;
     int b = i / nz, j = i % nz;
-    mu[i] = out12[(long)b * 2 * NZp + j];
-    logvar[i] = out12[(long)b * 2 * NZp + NZp + j];
+    const float poison = (failed && *failed) ? __builtin_nanf("") : 0.f;  // see dvae_encode_forward
+    mu[i] = out12[(long)b * 2 * NZp + j] + poison;
+    logvar[i] = out12[(long)b * 2 * NZp + NZp + j] + poison;
 }
 __global__ void join_mu_logvar_kernel(float* d12, const float* dmu, const float* dlogvar, int B, int nz, int NZp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,6 +210,7 @@ struct EncWs {
     // backward
     float *dhs[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
     float *d12, *dhgu, *dhg;
+    float* sync;  // counters of the persistent chain kernel (chain.hip: enc_chain_fwd), used as unsigned storage
     size_t total;
 };
 static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
@@ -240,6 +243,7 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.d12 = b.take((size_t)c.B * 2 * d.NZp);
     w.dhgu = b.take((size_t)c.B * Hp);
     w.dhg = b.take((size_t)c.B * 2 * Hp);
+    w.sync = b.take(ENC_CHAIN_SYNC_WORDS);
     w.total = b.off;
     return w;
 }
@@ -371,6 +375,19 @@ static bool chain_fused(const Dims& d, int B) {
 // both encoder directions of a level as one grid (dvae_chain_level_batch) instead of two streams:
 // measured no faster forward (0.64 ms either way) and slower backward (1.08 -> 1.27 ms), because
 // workgroups launched together run in lockstep and nothing overlaps; kept behind DVAE_CHAIN_MERGE=1
+// the whole forward chain of the encoder as ONE persistent launch (chain.hip: enc_chain_fwd): DVAE_CHAIN_PERSIST=1
+static int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
+static bool chain_persist(const Dims& d, int B) {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_PERSIST"); return v ? atoi(v) : 0; }();
+    if (!knob || d.bf16 || d.bn) return false;
+    const long tiles = (long)cdiv(B, 64) * (d.Hp / 32);
+    return tiles <= 256 && tiles <= device_cu_count();
+}
 static bool chain_merge_dirs() {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_MERGE"); return v ? atoi(v) : 0; }();
     return knob != 0;
@@ -472,14 +489,28 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     // host is still issuing the other one's launches.
     // (optional, DVAE_CHAIN_MERGE=1: both directions of a level as ONE grid on the caller's stream,
     // dvae_chain_level_batch, instead of two streams)
-    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
+    const bool persist = chain_persist(d, c->B);
+    const bool merged = !persist && fused && dirs == 2 && !d.bn && chain_merge_dirs();
     Side* side = nullptr;
     SideGuard side_guard{side, s};
-    if (dirs == 2 && !merged) {
+    if (dirs == 2 && !merged && !persist) {
         DVAE_TRY(side_for_stream(s, &side));
         DVAE_TRY(fork_side(side, s));
     }
-    if (d.bn) {
+    if (persist) {
+        EncChainArgs a = {};
+        for (int k = 0; k < dirs; ++k) {
+            EncChainDir& e = a.d[k];
+            e.agg = w.agg[k]; e.gates = w.gates[k]; e.ghn = w.ghn[k]; e.hs = w.hs[k]; e.gm = w.gm[k]; e.msg = w.msg[k];
+            e.whh = pw + L.whh[k]; e.wgm = pw + L.wgm[k]; e.gi = pw + L.gi[k]; e.bhn = pw + L.bhn[k]; e.gv = pw + L.gv[k];
+            e.off = k == 0 ? bv.pred_off : bv.succ_off;
+            e.idx = k == 0 ? bv.pred_idx : bv.succ_idx;
+        }
+        a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = dirs;
+        a.sync = reinterpret_cast<unsigned*>(w.sync);
+        a.status = a.sync + ENC_CHAIN_SYNC_WORDS - 64;
+        DVAE_TRY(enc_chain_fwd(a, s));
+    } else if (d.bn) {
         if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
         DVAE_TRY(run_dir_bn(0, s));
     } else if (merged) {
@@ -513,7 +544,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
             DVAE_TRY(level(0, step, s));
         }
     }
-    if (dirs == 2 && !merged) DVAE_TRY(join_side(side, s));
+    if (dirs == 2 && !merged && !persist) DVAE_TRY(join_side(side, s));
     // graph state (models.py:704-718 / 1006-1027)
     DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
     const float* hgu = w.hg;
@@ -525,7 +556,9 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         ld_hgu = Hp;
     }
     DVAE_TRY(lin_fwd(hgu, ld_hgu, nullptr, pw + L.fc12, Hp, pw + L.b12, w.out12, 2 * d.NZp, B, 2 * d.NZp, Hp, 0, 0, s));
-    EW(split_mu_logvar_kernel, (long)B * d.nz, w.out12, mu, logvar, B, d.nz, d.NZp);
+    // (a persistent chain whose bounded wait ran out leaves its flag set: mu and logvar become NaN, never stale numbers)
+    EW(split_mu_logvar_kernel, (long)B * d.nz, w.out12, mu, logvar, B, d.nz, d.NZp,
+       persist ? reinterpret_cast<const unsigned*>(w.sync) + ENC_CHAIN_SYNC_WORDS - 64 : nullptr);
     return DVAE_OK;
 }
 
