@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32),
                 ("act", C.c_int32), ("accumulate", C.c_int32), ("relu_mask", C.c_void_p),
-                ("b_rows_bound", C.c_int32)]
+                ("b_rows_bound", C.c_int32), ("a_bf16", C.c_int32), ("b_bf16", C.c_int32)]
 
 
 class DvaeHipError(RuntimeError):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "dvae_version": (_I, []),
     "dvae_gemm_f32": (_I, [C.POINTER(GemmDesc), _P]),
     "dvae_gemm_bf16": (_I, [C.POINTER(GemmDesc), _P]),
+    "dvae_f32_to_bf16": (_I, [_P, _P, C.c_int64, _P]),
     "dvae_debug_set_kmajor_span_limit": (_I, [C.c_int64]),
     "dvae_gather_sum_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "dvae_scatter_rows_add_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P]),

@@ -441,6 +441,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
     static const int knob_log = env_int("DVAE_GEMM_LOG"), knob_tile = env_int("DVAE_GEMM_TILE"),
                      knob_split = env_int("DVAE_GEMM_SPLIT");
     DVAE_TRY(gemm_check(d, 32));
+    DVAE_REQUIRE(!d.a_bf16 && !d.b_bf16, "gemm_f32: bf16-stored operands belong to dvae_gemm_bf16");
     if (knob_log)
         fprintf(stderr, "GEMM %d %d %d akm=%d bkm=%d acc=%d bias=%d act=%d ar=%d br=%d cr=%d\n", d.M, d.N, d.K, d.a_kmajor,
                 d.b_kmajor, d.accumulate, d.bias != nullptr, d.act, d.a_rows != nullptr, d.b_rows != nullptr,

@@ -259,6 +259,11 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     DVAE_TRY(gemm_check(d, 4));
     if (d.M == 0 || d.N == 0) return DVAE_OK;
+    {   // two K-contiguous operands, bf16- or fp32-stored: the large-tile kernels of gemm_bf16_nn.hip
+        const int rc = gemm_bf16_nn(d, s);
+        if (rc <= 0) return rc;
+        if (d.a_bf16 || d.b_bf16) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands must be K-contiguous");
+    }
     dvae_gemm_desc sub;
     int k0 = 0;
     // a K-major operand is addressed with 32-bit byte offsets: contractions over more than 4 GiB

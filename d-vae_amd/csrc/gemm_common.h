@@ -138,6 +138,7 @@ inline bool gemm_vec_epilogue_ok(const GemmParams& p) {
 }
 
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16.hip
+int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16_nn.hip: 1 = not served there
 int gemm_check(const dvae_gemm_desc& d, int kmult);     // gemm.hip: argument checks common to both
 double kmajor_span_limit();                              // bytes a K-major operand may span (32-bit offsets)
 int gemm_k_chunk(const dvae_gemm_desc& d, int bk);

@@ -62,6 +62,10 @@ typedef struct dvae_gemm_desc {
                                b_rows is below it).  Required there: K-major operands are addressed with 32-bit byte
                                offsets, and a gather cannot be rebased chunk by chunk, so b_rows_bound * ldb * 4 must
                                stay below 4 GiB or the call is refused.  Ignored otherwise. */
+    int32_t a_bf16, b_bf16; /* dvae_gemm_bf16 only, K-contiguous operands only: the operand is STORED as bf16 (A / B then
+                               point at uint16 bf16 words, lda / ldb count bf16 elements; 16-byte aligned rows,
+                               K % 8 == 0).  Half the operand bytes and no conversion in the K loop: see
+                               gemm_bf16_nn.hip.  dvae_gemm_f32 refuses them. */
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
 /* Diagnostics: lowers the span (bytes from its base pointer) a K-major operand may cover, normally
@@ -74,6 +78,9 @@ int dvae_debug_set_kmajor_span_limit(int64_t bytes);
  * operands and result stay fp32 in memory.  K-contiguous operands need only
  * K % 4 == 0.  This is the reduced-precision mode of dvae_model_desc.mfma_bf16. */
 int dvae_gemm_bf16(const dvae_gemm_desc* d, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even), n % 4 == 0: makes the bf16 operand copies that a_bf16 / b_bf16 name.
+ * No counterpart in the reference (which has no reduced-precision mode). */
+int dvae_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
 /* out[r][0:width] (+)= sum_{k in [off[r], off[r+1])} src[idx[k]][0:width]
  * The gated-sum over predecessors of models.py:661-669 (padding rows of the

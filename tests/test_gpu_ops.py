@@ -19,6 +19,7 @@ def _s():
 def _gemm(A, B, Cm, M, N, K, akm=0, bkm=0, a_rows=None, b_rows=None, c_rows=None, bias=None, act=0, acc=0,
           bf16=False):
     d = L.GemmDesc()
+    d.a_bf16, d.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
     d.a_rows = a_rows.data_ptr() if a_rows is not None else None
     d.b_rows = b_rows.data_ptr() if b_rows is not None else None
@@ -489,6 +490,54 @@ def test_gemm_bf16_nt(M, N, K):
     _gemm(A, W, out, M, N, K, bf16=True)
     ref = _ref_bf16(A, W.t())
     assert (out - ref).abs().max() <= 2e-6 * K ** 0.5 * 16
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (1100, 1300, 200), (2048, 3072, 1024), (5000, 4096, 136)])
+@pytest.mark.parametrize("store", ["bf16xbf16", "f32xbf16", "bf16xf32", "f32xf32"])
+def test_gemm_bf16_stored_operands(M, N, K, store, monkeypatch):
+    """gemm_bf16_nn.hip: K-contiguous operands stored as bf16 or fp32, each side independently; 128 x 128 tiles for
+    small products, 256 x 256 from three quarters of a round of the chip (the two large shapes), ragged M / N / K
+    edges, row gather + scatter + bias + relu + accumulate through the shared epilogue.  The fp32-stored form must
+    agree with the bf16-stored one exactly: both feed the matrix unit the same rounded values."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    X = torch.randn(M + 77, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    a_rows = torch.randperm(M + 77, device="cuda", generator=g)[:M].int()
+    c_rows = torch.randperm(M + 9, device="cuda", generator=g)[:M].int()
+    sa, sb = store.split("x")
+    Xs = X.bfloat16() if sa == "bf16" else X
+    Ws = W.bfloat16() if sb == "bf16" else W
+    if store == "f32xf32" and M * N < 256 * 256 * 192:
+        pytest.skip("small fp32-stored products stay on gemm_bf16.hip (covered by the tests around this one)")
+    out = torch.ones(M + 9, N, device="cuda")
+    _gemm(Xs, Ws, out, M, N, K, a_rows=a_rows, c_rows=c_rows, bias=bias, act=1, acc=1, bf16=True)
+    y = torch.relu(_ref_bf16(X[a_rows.long()], W.t()) + bias)
+    ref = torch.ones(M + 9, N, device="cuda")
+    ref[c_rows.long()] += y
+    assert (out - ref).abs().max() <= 2e-6 * K ** 0.5 * 16 + 1e-5
+    plain = torch.zeros(M, N, device="cuda")
+    _gemm(Xs, Ws, plain, M, N, K, bf16=True)
+    both = torch.zeros(M, N, device="cuda")
+    _gemm(X.bfloat16(), W.bfloat16(), both, M, N, K, bf16=True)
+    assert torch.equal(plain, both)
+
+
+def test_gemm_bf16_stored_operand_rules():
+    A = torch.randn(64, 64, device="cuda").bfloat16()
+    W = torch.randn(64, 64, device="cuda").bfloat16()
+    out = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(L.DvaeHipError, match="must be K-contiguous"):
+        _gemm(A, W, out, 64, 64, 64, bkm=1, bf16=True)
+    with pytest.raises(L.DvaeHipError, match="belong to dvae_gemm_bf16"):
+        _gemm(A, W, out, 64, 64, 64)
+    with pytest.raises(L.DvaeHipError, match="K % 8"):
+        _gemm(A, W, out, 64, 64, 60, bf16=True)
+    src = torch.randn(1000, device="cuda")
+    dst = torch.empty(1000, device="cuda", dtype=torch.bfloat16)
+    L.check(L.load().dvae_f32_to_bf16(src.data_ptr(), dst.data_ptr(), 1000, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src.bfloat16())
 
 
 def test_gemm_bf16_layout_identity_check():

@@ -28,10 +28,13 @@ SHAPES = [
     ("wgrad Wgm       ", 1024, 512, 8192, 1, 1, 1),
     ("square 4096     ", 4096, 4096, 4096, 0, 0, 0),
     ("square 8192     ", 8192, 8192, 8192, 0, 0, 0),
+    ("cfg5 GRU level  ", 2048, 3072, 1024, 0, 0, 0),
+    ("cfg5 EB fwd     ", 457494, 4096, 1024, 0, 0, 0),
 ]
 
 
 BF16 = os.environ.get("DVAE_GEMM_BF16") == "1"
+STORE = os.environ.get("DVAE_GEMM_STORE", "f32xf32")  # with DVAE_GEMM_BF16=1: how A x B are stored (K-contiguous shapes only)
 PEAK = 2500.0 if BF16 else 157.3
 
 
@@ -41,6 +44,11 @@ def run(label, M, N, K, akm, bkm, acc, iters=20):
     B = torch.randn((K, N) if bkm else (N, K), device="cuda", generator=g)
     Cm = torch.zeros(M, N, device="cuda")
     d = L.GemmDesc()
+    if BF16 and not akm and not bkm:
+        sa, sb = STORE.split("x")
+        A = A.bfloat16() if sa == "bf16" else A
+        B = B.bfloat16() if sb == "bf16" else B
+        d.a_bf16, d.b_bf16 = int(sa == "bf16"), int(sb == "bf16")
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
     d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), N
     d.M, d.N, d.K = M, N, K
