@@ -23,49 +23,73 @@ typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
 constexpr int NBK = 64;          // K step
 constexpr int NLD = NBK + 8;     // LDS row stride, bf16 elements
 
+__device__ uint4 nn_zero16;  // zero-initialised: what a gathered load past the end of K reads
+
 // One operand tile: ROWS rows x 64 k, loaded by NT threads, 16 bytes per thread and pass.
-template <int ROWS, int NT, bool HALF>
+//   GATHER = false: buffer loads off a descriptor based at the tile's first row whose range ends with the matrix: one
+//     32-bit offset register per operand, and rows past the last one or k past the end of a ragged last step (the
+//     offset is then replaced by one out of range) read zeros -- no clamping, no select on the data, nothing conditional.
+//   GATHER = true (a row index list): per-row 64-bit addresses; past the end of K the ADDRESS is redirected to 16 bytes of
+//     zeros.  (A select on the loaded data makes hipcc branch around the LDS stores and drain the loads one by one.)
+template <int ROWS, int NT, bool HALF, bool GATHER>
 struct NnLoader {
-    static constexpr int EPT = HALF ? 8 : 4;        // elements per 16-byte unit
+    static constexpr int ES = HALF ? 2 : 4;         // bytes per element
+    static constexpr int EPT = 16 / ES;             // elements per 16-byte unit
     static constexpr int TPR = NBK / EPT;           // threads per row: 8 / 16
     static constexpr int RPP = NT / TPR;            // rows per pass
     static constexpr int PASSES = ROWS / RPP;
     static constexpr int LDS_ELEMS = ROWS * NLD;
     static_assert(ROWS % RPP == 0, "tile rows must be a multiple of the rows per pass");
     uint4 r[PASSES];
-    int ridx[PASSES];  // the (gathered, clamped) row
+    int ridx[GATHER ? PASSES : 1];  // GATHER: the (clamped) rows
     const char* base_;
     int ld_;
+    __amdgpu_buffer_rsrc_t rsrc_;
+    unsigned voff_, pass_;          // !GATHER: byte offset of this thread's unit in pass 0; bytes from pass to pass
 
-    __device__ __forceinline__ void init(const void* base, const int* rows, int ld, int r0, int rdim, int tid) {
-        base_ = reinterpret_cast<const char*>(base);
+    __device__ __forceinline__ void init(const void* base, const int* rows, int ld, int r0, int rdim, int kdim, int tid) {
         ld_ = ld;
+        if (GATHER) {
+            base_ = reinterpret_cast<const char*>(base);
 #pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            int rr = r0 + tid / TPR + RPP * i;
-            rr = rr < rdim ? rr : rdim - 1;  // clamped rows are computed but never stored
-            ridx[i] = rows ? rows[rr] : rr;
+            for (int i = 0; i < PASSES; ++i) {
+                int rr = r0 + tid / TPR + RPP * i;
+                rr = rr < rdim ? rr : rdim - 1;  // clamped rows are computed but never stored
+                ridx[i] = rows[rr];
+            }
+        } else {
+            const char* b0 = reinterpret_cast<const char*>(base) + (long)r0 * ld * ES;
+            const long bytes = ((long)(rdim - r0 - 1) * ld + kdim) * ES;  // to the end of the last row's K elements
+            rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b0), 0, bytes < 0xFFFFFFF0L ? (unsigned)bytes : OOB, 0x00020000);
+            voff_ = (unsigned)((tid / TPR) * ld * ES + (tid % TPR) * 16);
+            pass_ = (unsigned)(RPP * ld * ES);
         }
     }
     __device__ __forceinline__ void load(int k0, int kend, int tid) {
-        int kk = k0 + (tid % TPR) * EPT;
-        kk = kk < kend ? kk : kend - EPT;  // past the end: a valid address; zeroed at store()
+        const int kk = k0 + (tid % TPR) * EPT;
+        const bool ok = kk < kend;
 #pragma unroll
-        for (int i = 0; i < PASSES; ++i)
-            r[i] = *reinterpret_cast<const uint4*>(base_ + ((long)ridx[i] * ld_ + kk) * (HALF ? 2 : 4));
+        for (int i = 0; i < PASSES; ++i) {
+            if (GATHER) {
+                const char* src = base_ + ((long)ridx[i] * ld_ + kk) * ES;
+                r[i] = *reinterpret_cast<const uint4*>(ok ? src : reinterpret_cast<const char*>(&nn_zero16));
+            } else {
+                const unsigned off = ok ? voff_ + (unsigned)k0 * ES + i * pass_ : OOB;
+                r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_, off, 0, 0));
+            }
+        }
     }
-    __device__ __forceinline__ void store(__bf16* lds, int k0, int kend, int tid) {
+    __device__ __forceinline__ void store(__bf16* lds, int tid) {
         const int c = tid % TPR;
-        const bool ok = k0 + c * EPT < kend;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const int row = tid / TPR + RPP * i;
             if (HALF) {
-                *reinterpret_cast<uint4*>(lds + row * NLD + c * 8) = ok ? r[i] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(lds + row * NLD + c * 8) = r[i];
             } else {
                 const float4 v = __builtin_bit_cast(float4, r[i]);
                 nbf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                *reinterpret_cast<uint2*>(lds + row * NLD + c * 4) = ok ? __builtin_bit_cast(uint2, b) : make_uint2(0, 0);
+                *reinterpret_cast<uint2*>(lds + row * NLD + c * 4) = __builtin_bit_cast(uint2, b);
             }
         }
     }
@@ -76,12 +100,13 @@ __device__ __forceinline__ nbf16x8 nn_frag(const __bf16* lds, int roff, int s, i
     return *reinterpret_cast<const nbf16x8*>(lds + (roff + (lane & 31)) * NLD + (2 * s + (lane >> 5)) * 8);
 }
 
-template <int BM, int BN, int WM, int WN, bool AH, bool BH, bool SWAP>
+template <int BM, int BN, int WM, int WN, bool AH, bool BH, bool AG>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nn_kernel(GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    using LA = NnLoader<BM, NT, AH>;
-    using LB = NnLoader<BN, NT, BH>;
+    constexpr bool SWAP = true;  // transposed accumulation, 16-byte epilogue (gemm_common.h); the launcher checks its conditions
+    using LA = NnLoader<BM, NT, AH, AG>;
+    using LB = NnLoader<BN, NT, BH, false>;
     constexpr int STAGE = LA::LDS_ELEMS + LB::LDS_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
 
@@ -106,13 +131,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nn_kernel(GemmParams p
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         LA la; LB lb;
-        la.init(p.A, p.a_rows, p.lda, m0, p.M, tid);
-        lb.init(p.B, p.b_rows, p.ldb, n0, p.N, tid);
+        la.init(p.A, p.a_rows, p.lda, m0, p.M, p.K, tid);
+        lb.init(p.B, nullptr, p.ldb, n0, p.N, p.K, tid);
         auto tile = [&](int t) { int k = kbeg + t * NBK; return k < kend ? k : kbeg; };  // past the end: loaded, never used
         la.load(tile(0), kend, tid);
         lb.load(tile(0), kend, tid);
-        la.store(lds, tile(0), kend, tid);
-        lb.store(lds + LA::LDS_ELEMS, tile(0), kend, tid);
+        la.store(lds, tid);
+        lb.store(lds + LA::LDS_ELEMS, tid);
         la.load(tile(1), kend, tid);
         lb.load(tile(1), kend, tid);
         __syncthreads();
@@ -136,11 +161,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nn_kernel(GemmParams p
                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
                 if (s == 1) {
                     // mid-step: staged registers (tile t+1) -> the other stage, then issue the loads of tile t+2
-                    la.store(lds + (cur ^ 1) * STAGE, tile(t + 1), kend, tid);
-                    lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tile(t + 1), kend, tid);
+                    la.store(lds + (cur ^ 1) * STAGE, tid);
+                    lb.store(lds + (cur ^ 1) * STAGE + LA::LDS_ELEMS, tid);
                     __builtin_amdgcn_sched_barrier(0);
                     la.load(tile(t + 2), kend, tid);
                     lb.load(tile(t + 2), kend, tid);
+                    __builtin_amdgcn_sched_barrier(0);  // (the loads must not sink below the MFMAs of the second half)
                 }
             }
             __syncthreads();
@@ -158,11 +184,11 @@ static int launch_nn(GemmParams p, bool ah, bool bh, int cus, hipStream_t s) {
     const long cap = BM == 256 ? cus : 2L * cus;  // 147 KB of LDS: one 256 x 256 workgroup per CU; 37 KB: several 128 x 128
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, p.split_k > 1 ? p.split_k : 1);
     dim3 block(WM * WN * 64);
-    const bool vec = gemm_vec_epilogue_ok(p);
-#define NN_LAUNCH(AH_, BH_)                                                                                       \
-    do {                                                                                                          \
-        if (vec) hipLaunchKernelGGL((gemm_bf16_nn_kernel<BM, BN, WM, WN, AH_, BH_, true>), grid, block, 0, s, p); \
-        else hipLaunchKernelGGL((gemm_bf16_nn_kernel<BM, BN, WM, WN, AH_, BH_, false>), grid, block, 0, s, p);    \
+    const bool ag = p.a_rows != nullptr;
+#define NN_LAUNCH(AH_, BH_)                                                                                     \
+    do {                                                                                                        \
+        if (ag) hipLaunchKernelGGL((gemm_bf16_nn_kernel<BM, BN, WM, WN, AH_, BH_, true>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((gemm_bf16_nn_kernel<BM, BN, WM, WN, AH_, BH_, false>), grid, block, 0, s, p);  \
     } while (0)
     if (ah && bh) NN_LAUNCH(true, true);
     else if (bh) NN_LAUNCH(false, true);
@@ -199,6 +225,10 @@ int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
     p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
     p.split_k = 1; p.k_per_split = 0;
+    if (d.b_rows || !gemm_vec_epilogue_ok(p)) {  // not built here: a gathered B, an output that cannot take 16-byte stores
+        if (typed) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands need N %% 4 == 0, ldc %% 4 == 0, 16-byte aligned C / bias, no b_rows");
+        return 1;
+    }
     if (big) return launch_nn<256, 256, 2, 4>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
     return launch_nn<128, 128, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
 }
