@@ -225,6 +225,7 @@ static int decode_impl(const dvae_model_desc* m, int32_t B, const float* pw, flo
     tl_bf16 = d.bf16;
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
+    set_mode(d, L, pw);
     GenWs w = carve_gen(d, B, ws);
     const int n = d.n, Hp = d.Hp, HEp = d.HEp, end_type = m->end_type;
     DecState st;

@@ -55,7 +55,16 @@ struct PackedLayout {
     size_t wv1, bv1, wv2, bv2;           // [2Hp][Hp], [2Hp], [Tp][2Hp], [Tp]
     size_t w1a, w1b, w1c, be1, we2, be2; // [HEp][Hp] x3, [HEp], [HEp], [4]
     size_t wu, bu;                       // [Hp][2Hp], [Hp]
-    size_t total;
+    size_t total;                        // floats of the fp32 part (also the size of the packed GRADIENT buffer's live part)
+    // bf16 mode only (dvae_model_desc.mfma_bf16): bf16 operand copies behind the fp32 part, rebuilt by every (re)pack
+    //   half  (float offset): bf16 copy of [0, total), element for element
+    //   halfT (float offset): the matrices below once more, TRANSPOSED ([cols][rows] bf16), so that a data gradient
+    //                         dX = dY W is a product of two K-contiguous operands too (gemm_bf16_nn.hip)
+    struct Mat { size_t off; int rows, cols; size_t toff; };  // off: floats into the fp32 part; toff: bf16 elements into halfT
+    Mat mats[20];
+    int nmats;
+    size_t half, halfT;
+    size_t alloc;                        // floats of the whole buffer (== total in fp32 mode)
 };
 
 static inline PackedLayout make_layout(const Dims& d) {
@@ -79,6 +88,23 @@ static inline PackedLayout make_layout(const Dims& d) {
     L.be1 = take(d.HEp); L.we2 = take(d.HEp); L.be2 = take(4);
     L.wu = take(Hp * 2 * Hp); L.bu = take(Hp);
     L.total = o;
+    L.nmats = 0; L.half = L.halfT = 0; L.alloc = o;
+    if (d.bf16) {
+        size_t t = 0;
+        auto mat = [&](size_t off, size_t rows, size_t cols) {
+            L.mats[L.nmats++] = PackedLayout::Mat{off, (int)rows, (int)cols, t};
+            t += (rows * cols + 63) & ~(size_t)63;
+        };
+        for (int g = 0; g < 3; ++g) mat(L.whh[g], 3 * Hp, Hp);
+        for (int k = 0; k < 2; ++k) mat(L.wgm[k], 2 * Hp, Hp);
+        mat(L.fc12, 2 * d.NZp, Hp); mat(L.fc3, Hp, d.NZp);
+        mat(L.wv1, d.HVp, Hp); mat(L.wv2, d.Tp, d.HVp);
+        mat(L.w1a, d.HEp, Hp); mat(L.w1b, d.HEp, Hp); mat(L.w1c, d.HEp, Hp);
+        mat(L.wu, Hp, 2 * Hp);
+        L.half = take(L.total / 2);
+        L.halfT = take((t + 1) / 2);
+        L.alloc = o;
+    }
     return L;
 }
 

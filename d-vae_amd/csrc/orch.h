@@ -11,8 +11,51 @@ namespace dvae {
 // Matrix-unit input type of the call in progress (dvae_model_desc.mfma_bf16), set by every
 // entry point before it enqueues anything.
 static thread_local int tl_bf16 = 0;
+// bf16 mode: the packed weights of the call in progress and their layout (the bf16 copies behind the fp32 part)
+static thread_local const float* tl_pw = nullptr;
+static thread_local PackedLayout tl_layout;
+static inline void set_mode(const Dims& d, const PackedLayout& L, const float* pw) {
+    tl_bf16 = d.bf16;
+    tl_pw = d.bf16 ? pw : nullptr;
+    if (d.bf16) tl_layout = L;
+}
+// A product whose B operand is a packed weight matrix reads the bf16 copy instead (half the bytes, no conversion in the
+// K loop), and a data gradient (B K-major = the weight as stored) reads the TRANSPOSED bf16 copy, which makes it a
+// product of two K-contiguous operands: both then run on gemm_bf16_nn.hip.  Anything the copies cannot serve
+// (alignment, a sub-block that does not start on 8 elements, a gathered B) stays as it is.
+static inline void use_bf16_weight_copy(dvae_gemm_desc& g) {
+    static const int knob = getenv("DVAE_BF16_WEIGHTS") ? atoi(getenv("DVAE_BF16_WEIGHTS")) : 1;  // 0: off (A/B runs)
+    const PackedLayout& L = tl_layout;
+    if (!knob || !tl_pw || g.a_kmajor || g.b_rows || g.B < tl_pw || g.B >= tl_pw + L.total) return;
+    if (g.N % 4 || g.ldc % 4 || (uintptr_t)g.C % 16 || (uintptr_t)g.bias % 16 || (uintptr_t)g.relu_mask % 16 || g.K % 8) return;
+    const size_t off = (size_t)(g.B - tl_pw);
+    const uint16_t* half = reinterpret_cast<const uint16_t*>(tl_pw + L.half);
+    const uint16_t* halfT = reinterpret_cast<const uint16_t*>(tl_pw + L.halfT);
+    if (!g.b_kmajor) {
+        if (off % 8 || g.ldb % 8) return;
+        g.B = reinterpret_cast<const float*>(half + off);
+        g.b_bf16 = 1;
+        return;
+    }
+    for (int i = 0; i < L.nmats; ++i) {
+        const PackedLayout::Mat& m = L.mats[i];
+        if (off < m.off || off >= m.off + (size_t)m.rows * m.cols) continue;
+        if (g.ldb != m.cols) return;
+        const size_t r0 = (off - m.off) / m.cols, c0 = (off - m.off) % m.cols;
+        // the block is rows r0 .. r0 + K - 1 (the contraction), columns c0 .. c0 + N - 1 (the output columns) of W
+        if (r0 + g.K > (size_t)m.rows || c0 + g.N > (size_t)m.cols || m.rows % 8 || (c0 * m.rows + r0) % 8) return;
+        g.B = reinterpret_cast<const float*>(halfT + m.toff + c0 * m.rows + r0);
+        g.ldb = m.rows;
+        g.b_kmajor = 0;
+        g.b_bf16 = 1;
+        return;
+    }
+}
 static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s, int max_split = 0) {
-    return tl_bf16 ? gemm_bf16(g, s) : gemm(g, s, max_split);
+    if (!tl_bf16) return gemm(g, s, max_split);
+    dvae_gemm_desc h = g;
+    use_bf16_weight_copy(h);
+    return gemm_bf16(h, s);
 }
 
 // Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)

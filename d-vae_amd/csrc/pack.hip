@@ -229,6 +229,25 @@ int check_params(const Dims& d, const float* const* p) {
     return DVAE_OK;
 }
 
+// dst [cols][rows] bf16 = src [rows][cols] fp32, transposed (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        t[j][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) {
+            const __bf16 b = (__bf16)t[threadIdx.x][j];
+            dst[(size_t)c * rows + r] = __builtin_bit_cast(uint16_t, b);
+        }
+    }
+}
+
 }  // namespace dvae
 
 using namespace dvae;
@@ -236,7 +255,7 @@ using namespace dvae;
 extern "C" int64_t dvae_packed_floats(const dvae_model_desc* m) {
     Dims d;
     if (make_dims(m, d) != 0) return -1;
-    return (int64_t)make_layout(d).total;
+    return (int64_t)make_layout(d).alloc;  // bf16 mode: the fp32 part + the bf16 operand copies behind it (model.h)
 }
 
 static int pack_impl(const dvae_model_desc* m, const float* const* params, float* packed, bool zero_first, void* stream) {
@@ -265,7 +284,19 @@ static int pack_impl(const dvae_model_desc* m, const float* const* params, float
             table_op(ops, OP_BUILD_GV, d.n * d.H, params[gw[k]], params[gb[k]], params[mw[k]], packed + L.gv[k], nullptr,
                      nullptr, d.n, d.H, d.Hp, d.V, d.vid);
     }
-    return run_ops(ops, s);
+    DVAE_TRY(run_ops(ops, s));
+    if (d.bf16) {  // the bf16 operand copies (model.h: PackedLayout::half / halfT), rebuilt with every (re)pack
+        uint16_t* half = reinterpret_cast<uint16_t*>(packed + L.half);
+        uint16_t* halfT = reinterpret_cast<uint16_t*>(packed + L.halfT);
+        DVAE_TRY(dvae_f32_to_bf16(packed, half, (int64_t)L.total, s));
+        for (int i = 0; i < L.nmats; ++i) {
+            const PackedLayout::Mat& mt = L.mats[i];
+            const dim3 grid(cdiv(mt.cols, 32), cdiv(mt.rows, 32)), block(32, 8);
+            hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, s, packed + mt.off, halfT + mt.toff, mt.rows, mt.cols);
+        }
+        DVAE_LAUNCH_CHECK();
+    }
+    return DVAE_OK;
 }
 
 extern "C" int dvae_pack_weights(const dvae_model_desc* m, const float* const* params, float* packed, void* stream) {

@@ -433,6 +433,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     DVAE_REQUIRE(blob && pw && ws && mu && logvar, "dvae_encode_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
+    set_mode(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
@@ -572,6 +573,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     DVAE_REQUIRE(blob && pw && ws && dmu && dlogvar && pg, "dvae_encode_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
+    set_mode(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, NZ2 = 2 * d.NZp;
@@ -771,6 +773,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_REQUIRE(!training || eps, "dvae_loss_forward: training mode needs the normal draw eps");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
+    set_mode(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp;
@@ -898,6 +901,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_REQUIRE(blob && pw && ws && mu && logvar && g3 && dmu && dlogvar && pg, "dvae_loss_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
+    set_mode(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp, NST = nB + PT;
