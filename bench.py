@@ -245,6 +245,9 @@ def time_dominant_gemm(cfg, batch, iters=30, bf16=False):
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     fn = lib.dvae_gemm_bf16 if bf16 else lib.dvae_gemm_f32
+    if bf16:  # as in the step: fp32 activations x the bf16 copy of the weight (csrc/orch.h: use_bf16_weight_copy)
+        Wh = W.bfloat16()
+        d.B, d.b_bf16 = Wh.data_ptr(), 1
     for _ in range(3):
         dvae_amd._lib.check(fn(C.byref(d), sp))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -255,7 +258,8 @@ def time_dominant_gemm(cfg, batch, iters=30, bf16=False):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * HEp * Hp
-    return dict(kernel="gemm_bf16_kernel<128,128> (v_mfma_f32_32x32x16_bf16)" if bf16 else
+    big = ((M + 255) // 256) * ((HEp + 255) // 256) >= 192  # csrc/gemm_bf16_nn.hip: 256 x 256 tiles from 3/4 of a round
+    return dict(kernel=("gemm_bf16_nn_kernel<%s> fp32 x bf16-stored (v_mfma_f32_32x32x16_bf16)" % ("256,256" if big else "128,128")) if bf16 else
                 "gemm_f32_kernel<128,128> (v_mfma_f32_32x32x2_f32)", shape=[M, HEp, Hp],
                 avg_ms=ms, achieved=flops / (ms * 1e-3) / 1e12)
 

@@ -670,6 +670,10 @@ static int chain_launch_ks(ChainBatch& b, hipStream_t s) {
     }
     if (nk == 0) hipLaunchKernelGGL((chain_kernel<NGATE, WKM, TAIL, KS, 1, 0, ND>), grid, block, 0, s, b);
 #undef CHAIN_CASE
+    static const int knob_log = [] { const char* v = getenv("DVAE_GEMM_LOG"); return v ? atoi(v) : 0; }();
+    if (knob_log)  // one line per launch, as gemm.hip's (tools/roofline_by_kernel.py)
+        fprintf(stderr, "CHAINSEL chain_kernel<%d, %s, %d, %d, %d, %d, %d> %d %d %d\n", NGATE, WKM ? "true" : "false", TAIL, KS,
+                nk ? CHAIN_PF : 1, nk, ND, p.M * ND, NGATE * p.Hp, p.K);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

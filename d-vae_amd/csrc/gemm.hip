@@ -527,6 +527,9 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
     }
     // (a K step of 64 for the 64x64 tile was measured too: 6 % on the 1.5-tiles-per-CU GRU product,
     // nothing elsewhere, 1 % slower train step; only the 32-k kernels are built)
+    if (knob_log)  // one line per LAUNCH (tools/roofline_by_kernel.py maps launches to kernel families with it)
+        fprintf(stderr, "GEMMSEL %s %d %d %d akm=%d bkm=%d split=%d\n", small_m ? "32x128" : use128 ? "128x128" : "64x64", d.M, d.N,
+                d.K, d.a_kmajor, d.b_kmajor, p.split_k);
     if (small_m) return launch_cfg<32, 128, 1, 4, 32>(p, d.a_kmajor, d.b_kmajor, s);
     if (use128) return launch_cfg<128, 128, 2, 2, 32>(p, d.a_kmajor, d.b_kmajor, s);
     return launch_cfg<64, 64, 2, 2, 32>(p, d.a_kmajor, d.b_kmajor, s);

@@ -22,7 +22,11 @@ for src, dst in [("bench_cfg2.json", "bench_cfg2.json"), ("bench_cfg2_bf16.json"
     json.dump(last_json(os.path.join(P, src)), open(os.path.join(D, "%s_%s" % (r, dst)), "w"))
 shutil.copy(os.path.join(P, "stats_f32", "s_kernel_stats.csv"), os.path.join(D, "%s_bench_cfg2_kernel_stats.csv" % r))
 shutil.copy(os.path.join(P, "stats_bf16", "s_kernel_stats.csv"), os.path.join(D, "%s_bench_cfg2_bf16_kernel_stats.csv" % r))
-for f in ("gemm_shapes_fp32.txt", "gemm_shapes_bf16.txt", "phase_times_cfg2.txt"):
+for f in ("gemm_shapes_fp32.txt", "gemm_shapes_bf16.txt", "phase_times_cfg2.txt", "launch_log_cfg2.txt",
+          "phase_times_cfg5_bf16.txt", "host_cost_cfg1.txt", "gemm_shapes_bf16_f32xf32.txt", "gemm_shapes_bf16_f32xbf16.txt",
+          "gemm_shapes_bf16_bf16xbf16.txt"):
+    if not os.path.exists(os.path.join(P, f)):
+        continue
     txt = "".join(l for l in open(os.path.join(P, f)) if "amdgpu.ids" not in l)
     open(os.path.join(D, "%s_%s" % (r, f)), "w").write(txt)
 
@@ -35,7 +39,9 @@ for tag in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
     for k, v in acc.items():
         pm[k] = (sum(v) / len(v), len(v))
 print("PMC:", pm)
-json.dump({k: {"mean": v[0], "launches": v[1]} for k, v in pm.items()}, open(os.path.join(D, "%s_gemm_pmc.json" % r), "w"), indent=1)
+pmj = {k: {"mean": v[0], "launches": v[1]} for k, v in pm.items()}
+pmj["shape_MNK"] = [9251, 2048, 512]  # tools/profile_round.sh: gemm_one.py 9251 2048 512 (the EB product of cfg 2)
+json.dump(pmj, open(os.path.join(D, "%s_gemm_pmc.json" % r), "w"), indent=1)
 
 allp = os.path.join(ROOT, "gpurun_out", "bench_all.jsonl")
 if os.path.exists(allp):

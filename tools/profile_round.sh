@@ -19,3 +19,9 @@ timeout -k 10 300 python bench.py --dtype bf16 > $O/bench_cfg2_bf16.json 2> $O/b
 timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_fp32.txt 2>&1 || exit 1
 DVAE_GEMM_BF16=1 timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_bf16.txt 2>&1 || exit 1
 timeout -k 10 100 python tools/phase_times.py > $O/phase_times_cfg2.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/roofline_by_kernel.py --log $O/launch_log_cfg2.txt > $O/launch_log.out 2>&1 || exit 1
+timeout -k 10 200 python tools/phase_times.py cfg5 4 bf16 > $O/phase_times_cfg5_bf16.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/host_cost.py cfg1 10 > $O/host_cost_cfg1.txt 2>&1 || exit 1
+for st in f32xf32 f32xbf16 bf16xbf16; do
+  DVAE_GEMM_BF16=1 DVAE_GEMM_STORE=$st timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_bf16_$st.txt 2>&1 || exit 1
+done
