@@ -8,7 +8,7 @@
 //   * operands stored as bf16 (weights: a bf16 copy made once per optimizer step beside the packed fp32 master copy;
 //     activations: written as bf16 by the kernel that produces them) -- half the bytes, no conversion in the loop;
 //   * 256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 per wave: 8 accumulator blocks), 147 KB of LDS, one workgroup per CU.
-// A 128 x 128 / 4-wave instance serves products too small for 256 CUs' worth of 256 x 256 tiles.
+// 128 x 128 and 64 x 64 / 4-wave instances serve products too small for 256 CUs' worth of 256 x 256 tiles.
 //
 // LDS image of either operand: [rows][64 + 8] bf16 (as gemm_bf16.hip): a lane's MFMA fragment is one ds_read_b128, the
 // 144-byte row stride spreads a 16-lane group over all banks.  Register-staged double buffering: the next tile is
@@ -181,7 +181,7 @@ static int launch_nn(GemmParams p, bool ah, bool bh, int cus, hipStream_t s) {
     p.tiles_x = cdiv(p.N, BN);
     p.tiles_y = cdiv(p.M, BM);
     const long ntiles = (long)p.tiles_x * p.tiles_y;
-    const long cap = BM == 256 ? cus : 2L * cus;  // 147 KB of LDS: one 256 x 256 workgroup per CU; 37 KB: several 128 x 128
+    const long cap = BM == 256 ? cus : BM == 128 ? 2L * cus : 4L * cus;  // 147 KB of LDS: one 256 x 256 workgroup per CU; 37 / 18 KB: several
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, p.split_k > 1 ? p.split_k : 1);
     dim3 block(WM * WN * 64);
     const bool ag = p.a_rows != nullptr;
@@ -203,7 +203,7 @@ static int launch_nn(GemmParams p, bool ah, bool bh, int cus, hipStream_t s) {
 // product is not one this file serves (the caller then runs its own kernel), 0 / negative as usual otherwise.
 int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
     if (d.a_kmajor || d.b_kmajor) return 1;
-    static const int knob = getenv("DVAE_GEMM_NN") ? atoi(getenv("DVAE_GEMM_NN")) : 1;  // 0: never, 128 / 256: force the tile
+    static const int knob = getenv("DVAE_GEMM_NN") ? atoi(getenv("DVAE_GEMM_NN")) : 1;  // 0: never, 64 / 128 / 256: force the tile
     const bool typed = d.a_bf16 || d.b_bf16;
     if (!knob && !typed) return 1;
     const int ea = d.a_bf16 ? 8 : 4, eb = d.b_bf16 ? 8 : 4;
@@ -214,10 +214,12 @@ int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const long t256 = (long)cdiv(d.M, 256) * cdiv(d.N, 256);
+    const long t256 = (long)cdiv(d.M, 256) * cdiv(d.N, 256), t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     bool big = t256 >= (3L * cus) / 4;  // at least three quarters of a round of the chip
+    bool mid = t128 >= (3L * cus) / 2;  // as gemm_bf16.hip: 128 x 128 tiles from one and a half rounds, 64 x 64 below
     if (knob == 256) big = true;
-    if (knob == 128) big = false;
+    if (knob == 128) { big = false; mid = true; }
+    if (knob == 64) big = mid = false;
     if (!big && !typed && knob == 1) return 1;  // small fp32-stored products: gemm_bf16.hip's tuned tile / split-K choice
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C;
@@ -230,7 +232,8 @@ int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
         return 1;
     }
     if (big) return launch_nn<256, 256, 2, 4>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
-    return launch_nn<128, 128, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
+    if (mid) return launch_nn<128, 128, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
+    return launch_nn<64, 64, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n4) {

@@ -37,6 +37,9 @@ static inline void use_bf16_weight_copy(dvae_gemm_desc& g) {
         g.b_bf16 = 1;
         return;
     }
+    // (a small accumulating data gradient is better off with split-K over the fp32 weight, gemm_bf16.hip: the
+    // K-contiguous kernels do not split K)
+    if (g.accumulate && (long)cdiv(g.M, 64) * cdiv(g.N, 64) < 256) return;
     for (int i = 0; i < L.nmats; ++i) {
         const PackedLayout::Mat& m = L.mats[i];
         if (off < m.off || off >= m.off + (size_t)m.rows * m.cols) continue;
