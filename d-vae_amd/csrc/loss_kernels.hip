@@ -154,6 +154,126 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
     }
 }
 
+// The same forward for wide tables (HEp > 2048): the FOUR waves of a workgroup share a pair, wave w taking the hidden
+// units of iterations 4 w .. 4 w + 3 (NITW = NIT / 4 iterations of 256 units each; same lane -> unit map and the same
+// mask bits as above, a wave's 16 bits being one half of a mask word).  With a whole 4096-unit row per wave the per-pair
+// values (relu outputs for the w2 gradient, mask words) take 230 VGPRs: two waves per SIMD, each waiting on its own 64
+// loads -- the kernel ran at a fraction of the L2 rate (cfg 5: 22.6 ms for 4.1 M pairs).  A quarter row per wave is
+// ~70 VGPRs; the four partial sums of a pair meet through LDS (one barrier per pair, double-buffered slots).
+template <int NITW>
+__global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __restrict__ ea, const float* __restrict__ eb,
+                                                             const float* __restrict__ ec, const int* __restrict__ pair_a,
+                                                             const int* __restrict__ pair_h, const int* __restrict__ pair_c,
+                                                             const uint8_t* __restrict__ pair_t, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ dl, float* __restrict__ loss_sum,
+                                                             uint32_t* __restrict__ mask, float* __restrict__ dw2_partial,
+                                                             int n_pairs, int HEp, float* __restrict__ sums,
+                                                             unsigned tickets, float beta, float* __restrict__ out3,
+                                                             int group) {
+    static_assert(NITW == 4, "a wave's mask bits are one 16-bit half of a word: 4 iterations x 4 units");
+    constexpr int NW = (4 * NITW + 7) / 8;  // mask words per pair and lane
+    extern __shared__ float sh[];  // [HEp] workgroup sum of the w2-gradient partials, then 8 exchange slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (dw2_partial) {
+        for (int c = threadIdx.x; c < HEp; c += 256) sh[c] = 0.f;
+    }
+    float* xch = sh + HEp;
+    float local = 0.f;
+    const float bias2 = b2[0];
+    float aw[NITW * 4];
+#pragma unroll
+    for (int i = 0; i < NITW * 4; ++i) aw[i] = 0.f;
+    // pairs of this workgroup.  `group` > 0 (runs of `group` pairs = the pairs of one graph, which share table rows: a
+    // graph's pairs touch 1 MB of EA and ~3.6 MB of EB rows at cfg 5, each EB row ~9 times): the workgroups that share
+    // an XCD (blockIdx % 8) work through the SAME graph together, pair k of the graph going to workgroup k mod J of the
+    // XCD's J, so that the XCD's L2 (4 MB) holds one graph's rows while they are re-read, instead of every workgroup
+    // streaming a graph of its own from HBM (4.1 M pairs x 32 KB = 132 GB per pass).  Otherwise: every gridDim.x-th pair.
+    const int n_groups = group > 0 ? (n_pairs + group - 1) / group : 0;
+    const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, j = blockIdx.x >> 3;
+    const bool coop = group > 0 && (gridDim.x & 7) == 0 && J > 0;
+    const int per_graph = coop ? (group + J - 1) / J : group;  // iterations a workgroup spends on one graph
+    const int iters = coop ? ((n_groups + 7) / 8) * per_graph
+                           : group > 0 ? ((n_groups + gridDim.x - 1) / gridDim.x) * group : (n_pairs + gridDim.x - 1) / gridDim.x;
+    uint16_t* mask16 = reinterpret_cast<uint16_t*>(mask);
+    int executed = 0;
+    for (int it = 0; it < iters; ++it) {
+        int p;
+        if (coop) {
+            const int run = xcd + 8 * (it / per_graph), k = j + J * (it % per_graph);
+            p = (run < n_groups && k < group) ? run * group + k : n_pairs;
+        } else if (group > 0) {
+            const int run = blockIdx.x + (it / group) * gridDim.x;
+            p = run < n_groups ? run * group + it % group : n_pairs;
+        } else {
+            p = blockIdx.x + it * gridDim.x;
+        }
+        if (p >= n_pairs) continue;  // uniform over the workgroup
+        const float* ra = ea + (long)pair_a[p] * HEp;
+        const float* rb = eb + (long)pair_h[p] * HEp;
+        const float* rc = ec ? ec + (long)pair_c[p] * HEp : nullptr;
+        float rv[NITW * 4];
+        uint32_t bits16 = 0u;
+        float s = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < NITW; ++ii) {
+            const int c = lane * 4 + 256 * (wave * NITW + ii);
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < HEp) {
+                float4 a = ld4c(ra + c), b = ld4c(rb + c), bb = ld4c(b1 + c), w = ld4c(w2 + c);
+                float4 pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
+                if (rc) {
+                    float4 cc = ld4c(rc + c);
+                    pre.x += cc.x; pre.y += cc.y; pre.z += cc.z; pre.w += cc.w;
+                }
+                r = make_float4(fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f));
+                const uint32_t b4 = (pre.x > 0.f ? 1u : 0u) | (pre.y > 0.f ? 2u : 0u) | (pre.z > 0.f ? 4u : 0u) |
+                                    (pre.w > 0.f ? 8u : 0u);
+                bits16 |= b4 << (4 * ii);
+                s += w.x * r.x + w.y * r.y + w.z * r.z + w.w * r.w;
+            }
+            rv[4 * ii + 0] = r.x; rv[4 * ii + 1] = r.y; rv[4 * ii + 2] = r.z; rv[4 * ii + 3] = r.w;
+        }
+        s = wave_sum(s);
+        float* slot = xch + 4 * (executed++ & 1);  // (parity of the pairs actually run: skipped iterations take no barrier)
+        if (lane == 0) slot[wave] = s;
+        __syncthreads();  // (the slots of pair it - 1 are free again: every wave passed this barrier after reading them)
+        s = slot[0] + slot[1] + slot[2] + slot[3] + bias2;  // the same order in every wave
+        float prob = 1.f / (1.f + expf(-s));
+        float t = (float)pair_t[p];
+        float lp = fmaxf(logf(prob), -100.f);
+        float lq = fmaxf(logf(1.f - prob), -100.f);
+        float pq = prob * (1.f - prob);
+        float g = (prob - t) / fmaxf(pq, 1e-12f) * pq;
+        if (threadIdx.x == 0) {
+            local += -(t * lp + (1.f - t) * lq);
+            dl[p] = g;
+        }
+        if (mask)  // iterations 4 w .. 4 w + 3 = nibbles 4 (w % 2) .. + 3 of word w / 2: its low or high half
+            mask16[(((long)p * NW + (wave >> 1)) * 64 + lane) * 2 + (wave & 1)] = (uint16_t)bits16;
+        if (dw2_partial) {
+#pragma unroll
+            for (int i = 0; i < NITW * 4; ++i) aw[i] += g * rv[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (local != 0.f) atomicAdd(loss_sum, local);
+        if (sums) loss_ticket(sums, tickets, beta, out3);
+    }
+    if (dw2_partial) {  // uniform; the waves own disjoint hidden units
+#pragma unroll
+        for (int ii = 0; ii < NITW; ++ii) {
+            const int c = lane * 4 + 256 * (wave * NITW + ii);
+            if (c < HEp) {
+                sh[c + 0] = aw[4 * ii + 0]; sh[c + 1] = aw[4 * ii + 1]; sh[c + 2] = aw[4 * ii + 2]; sh[c + 3] = aw[4 * ii + 3];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < HEp; c += 256) dw2_partial[(long)blockIdx.x * HEp + c] = sh[c];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // grouped backward: one wave per chunk of pairs that share one row of an edge-predictor table.
 //   chunk q covers grp_pairs[chunk_off[q] .. chunk_off[q+1]) (grp_pairs == NULL: the pair ids
@@ -195,6 +315,51 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const int* __restrict__ c
             if (c < HEp) {
                 float4 w = ld4c(w2 + c);
                 float4 v = make_float4(acc[4 * i] * w.x, acc[4 * i + 1] * w.y, acc[4 * i + 2] * w.z, acc[4 * i + 3] * w.w);
+                float* d = dtab + (long)row * HEp + c;
+                if (cr < 0) {
+                    atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+                } else {
+                    *reinterpret_cast<float4*>(d) = v;
+                }
+            }
+        }
+    }
+}
+
+// Wide tables (HEp > 2048): a wave takes a QUARTER of a chunk's row (iterations 4 w .. 4 w + 3: one 16-bit half of a
+// mask word per pair), so that 16 accumulators per lane replace 64 (130 VGPRs, three waves per SIMD, before).
+__global__ __launch_bounds__(256) void pair_bwd_split_kernel(const int* __restrict__ chunk_off,
+                                                             const int* __restrict__ chunk_row,
+                                                             const int* __restrict__ grp_pairs, const float* __restrict__ dl,
+                                                             const uint32_t* __restrict__ mask, const float* __restrict__ w2,
+                                                             const float* __restrict__ scale, float* __restrict__ dtab,
+                                                             int n_chunks, int HEp) {
+    constexpr int NW = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long waves_total = (long)gridDim.x * 4;
+    const float sc = scale ? scale[0] : 1.f;
+    const uint16_t* mask16 = reinterpret_cast<const uint16_t*>(mask);
+    for (long item = (long)blockIdx.x * 4 + wave; item < (long)n_chunks * 4; item += waves_total) {
+        const int q = (int)(item >> 2), w = (int)(item & 3);  // the four quarters of a chunk run in one workgroup
+        const int cr = chunk_row[q];
+        const int row = cr & 0x7fffffff;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int k1 = chunk_off[q + 1];
+        for (int k = chunk_off[q]; k < k1; ++k) {
+            const int p = grp_pairs ? grp_pairs[k] : k;
+            const float g = dl[p] * sc;
+            const uint32_t mw = mask16[(((long)p * NW + (w >> 1)) * 64 + lane) * 2 + (w & 1)];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += sel(mw, i, g);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int c = lane * 4 + 256 * (4 * w + ii);
+            if (c < HEp) {
+                float4 wv = ld4c(w2 + c);
+                float4 v = make_float4(acc[4 * ii] * wv.x, acc[4 * ii + 1] * wv.y, acc[4 * ii + 2] * wv.z, acc[4 * ii + 3] * wv.w);
                 float* d = dtab + (long)row * HEp + c;
                 if (cr < 0) {
                     atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
@@ -445,9 +610,16 @@ int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_
     const int nit = pair_nit(HEp);
     DVAE_REQUIRE(nit > 0, "pair_bce_fwd: HEp %d exceeds 4096", HEp);
     if (n_pairs == 0 && !dw2_partial && !sums) return DVAE_OK;
-    const size_t shm = ((size_t)HEp + 4) * sizeof(float);
+    const size_t shm = ((size_t)HEp + 8) * sizeof(float);
     dim3 grid(n_blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
+    static const int knob_split = getenv("DVAE_PAIR_SPLIT") ? atoi(getenv("DVAE_PAIR_SPLIT")) : 1;  // 0: one wave per pair at every width
+    if (nit == 16 && knob_split) {  // wide tables: four waves per pair
+        hipLaunchKernelGGL((pair_fwd_split_kernel<4>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2,
+                           b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3, group);
+        DVAE_LAUNCH_CHECK();
+        return DVAE_OK;
+    }
 #define DVAE_PAIR_FWD(N)                                                                                              \
     hipLaunchKernelGGL((pair_fwd_kernel<N>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, \
                        b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3, group)
@@ -484,6 +656,14 @@ extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t
     if (blocks > 8192) blocks = 8192;
     dim3 grid(blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
+    static const int knob_split = getenv("DVAE_PAIR_SPLIT") ? atoi(getenv("DVAE_PAIR_SPLIT")) : 1;
+    if (nit == 16 && knob_split) {  // wide tables: a quarter row per wave
+        grid.x = n_chunks < 16384 ? n_chunks : 16384;
+        hipLaunchKernelGGL(pair_bwd_split_kernel, grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, dtab,
+                           n_chunks, HEp);
+        DVAE_LAUNCH_CHECK();
+        return DVAE_OK;
+    }
 #define DVAE_PAIR_BWD(N)                                                                                            \
     hipLaunchKernelGGL((pair_bwd_kernel<N>), grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, \
                        dtab, n_chunks, HEp)

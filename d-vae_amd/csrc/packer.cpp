@@ -320,7 +320,11 @@ extern "C" int dvae_batch_create(int32_t B, int32_t max_n, int32_t nvt, int32_t 
     DVAE_REQUIRE(types && pred_mask && n_vertices && handle && counts, "dvae_batch_create: null pointer");
     PackedBatch* pb = new (std::nothrow) PackedBatch();
     DVAE_REQUIRE(pb != nullptr, "dvae_batch_create: out of memory");
-    int rc = build(*pb, B, max_n, nvt, start_type, is_bn, types, pred_mask, n_vertices, 16);
+    // pairs per chunk of the grouped backward (loss_kernels.hip): rows with more pairs are split into chunks that combine
+    // with atomics.  Large graphs (a vertex has up to max_n - 1 candidate predecessors, so a table row up to that many
+    // pairs) take whole rows: cfg 5's dEA pass otherwise issues 1.3 G float atomics per step.
+    const int chunk = max_n > 16 ? 64 : 16;
+    int rc = build(*pb, B, max_n, nvt, start_type, is_bn, types, pred_mask, n_vertices, chunk);
     if (rc != 0) { delete pb; return rc; }
     *handle = pb;
     *counts = pb->c;

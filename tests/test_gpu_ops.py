@@ -349,9 +349,10 @@ def test_pair_kernels_match_torch():
     assert (ea.grad.sum(0) - b1.grad).abs().max() < 1e-3  # db1 = column sum of dEA
 
 
-@pytest.mark.parametrize("HEp", [128, 384, 2048, 4096])
+@pytest.mark.parametrize("HEp", [128, 384, 2048, 3072, 4096])
 def test_pair_kernels_widths(HEp):
-    """every compiled width class of the pair kernels (1, 2, 8, 16 column iterations; 1 or 2 mask words)"""
+    """every compiled width class of the pair kernels (1, 2, 8, 16 column iterations; 1 or 2 mask words; above 2048
+    hidden units the four-waves-per-pair forward and the quarter-row backward)"""
     torch.manual_seed(HEp)
     NA, NB, NP = 9, 10, 60
     ea = torch.randn(NA, HEp, device="cuda", requires_grad=True)
