@@ -29,6 +29,9 @@ SHAPES = [
     ("square 4096     ", 4096, 4096, 4096, 0, 0, 0),
     ("square 8192     ", 8192, 8192, 8192, 0, 0, 0),
     ("cfg5 GRU level  ", 2048, 3072, 1024, 0, 0, 0),
+    ("cfg5 gate level ", 2048, 2048, 1024, 0, 0, 0),
+    ("cfg5 dGRU as NN ", 2048, 1024, 3072, 0, 0, 1),
+    ("cfg5 dgate as NN", 2048, 1024, 2048, 0, 0, 1),
     ("cfg5 EB fwd     ", 457494, 4096, 1024, 0, 0, 0),
 ]
 
