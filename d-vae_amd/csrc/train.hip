@@ -416,6 +416,9 @@ static int wbl_knob() {
     return knob;
 }
 static bool wgrad_by_level(int which = 1) { return (wbl_knob() & which) != 0; }
+// (bf16 mode, large levels -- cfg 5: 2048 rows x Hp 1024 -- the whole-pass products measured 1 % better; bit 2 of the
+// knob keeps the per-level terms there too)
+static bool wbl_size_ok(const Dims& d, int B) { return !d.bf16 || (long)B * d.Hp <= 1024L * 512 || (wbl_knob() & 4) != 0; }
 static int wbl_split() {
     static const int knob = [] { const char* v = getenv("DVAE_WBL_SPLIT"); return v ? atoi(v) : 0; }();
     return knob;
@@ -978,7 +981,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
         // (only the last vertex's rows of d gm are not written by the chain below)
         DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
-        const bool wbl = wgrad_by_level();
+        const bool wbl = wgrad_by_level() && wbl_size_ok(d, B);
         hipStream_t s2 = side->stream;
         if (wbl) {  // the partial rows' d gh is final: their term of dWhh starts the side stream's run beside the chain
             DVAE_TRY(fork_side(side, s));
@@ -1028,7 +1031,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     }
     // the GRU's remaining weight gradients go to the side stream, behind the predictors' and the per-level terms
     DVAE_TRY(fork_side(side, s));
-    const bool wbl_done = !d.bn && wgrad_by_level();
+    const bool wbl_done = !d.bn && wgrad_by_level() && wbl_size_ok(d, B);
     if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream));
     else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
     // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------

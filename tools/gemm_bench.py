@@ -33,6 +33,7 @@ SHAPES = [
     ("cfg5 dGRU as NN ", 2048, 1024, 3072, 0, 0, 1),
     ("cfg5 dgate as NN", 2048, 1024, 2048, 0, 0, 1),
     ("cfg5 EB fwd     ", 457494, 4096, 1024, 0, 0, 0),
+    ("cfg5 dEB as NN  ", 457494, 1024, 4096, 0, 0, 1),
 ]
 
 
