@@ -152,14 +152,20 @@ static int side_for_stream(hipStream_t caller, Side** out) {
         static const int prio_knob = [] { const char* v = getenv("DVAE_SIDE_PRIO"); return v ? atoi(v) : 0; }();
         int plo = 0, phi = 0;  // numerically greatest = lowest priority
         DVAE_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        // Fork / join events order kernels of two streams of ONE device.  A default event makes its record a
+        // system-scope fence (cache write-back and invalidation, hip_runtime_api.h: hipEventDisableSystemFence) that
+        // nothing here needs -- no host and no other device reads between a fork and its join -- and that the next
+        // kernels pay for with a cold L2.  DVAE_EVENT_FENCE=1 restores the default (A/B runs).
+        static const int fence_knob = [] { const char* v = getenv("DVAE_EVENT_FENCE"); return v ? atoi(v) : 0; }();
+        const unsigned evf = hipEventDisableTiming | (fence_knob ? 0u : (unsigned)hipEventDisableSystemFence);
         if (prio_knob & 1) DVAE_HIP(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, plo));
         else DVAE_HIP(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
-        DVAE_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
-        DVAE_HIP(hipEventCreateWithFlags(&sd->join, hipEventDisableTiming));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->fork, evf));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->join, evf));
         if (prio_knob & 2) DVAE_HIP(hipStreamCreateWithPriority(&sd->aux, hipStreamNonBlocking, plo));
         else DVAE_HIP(hipStreamCreateWithFlags(&sd->aux, hipStreamNonBlocking));
-        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_ev, hipEventDisableTiming));
-        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_join, hipEventDisableTiming));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_ev, evf));
+        DVAE_HIP(hipEventCreateWithFlags(&sd->aux_join, evf));
     }
     sd->last_use = ++g_side_clock;
     *out = sd;
