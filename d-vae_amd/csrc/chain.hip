@@ -504,6 +504,97 @@ __global__ __launch_bounds__(128 * KS) void chain_kernel(ChainBatch batch) {
     chain_body<NGATE, WKM, TAIL, KS, PF, NK, ND, false>(batch, lds, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------- small levels
+// The same level operations for FEW rows (batch 32: the reference's own training recipe, train.py: --batch-size 32).
+// chain_kernel's workgroup owns 64 rows and walks all of K: at 32 rows half of its MFMA work is padding, only Hp / 32 =
+// 16 workgroups exist, and a level costs the same 10 us of MFMA issue per workgroup as at 1024 rows.  Here a workgroup
+// owns 32 rows x 32 hidden units x all gates, its 4 waves a quarter of K each, and the operands go from global memory
+// STRAIGHT into MFMA fragments (lane (row | column, half h) loads 8 consecutive k of its row: no LDS image, no barrier
+// in the K loop; the whole operand set of a level is a few MB and L2-resident).  The quarter sums meet through LDS in
+// K order and run the same tails (chain_epilogue with one row block).  Deterministic; same arithmetic per element as
+// chain_kernel up to the order of the K partial sums.
+template <int NGATE, bool WKM, int TAIL>
+__global__ __launch_bounds__(256) void chain_small_kernel(ChainParams p) {
+    constexpr int KS = 4;
+    __shared__ __attribute__((aligned(16))) float lds[4 * (KS - 1) * 2 * NGATE * 64 * 4];  // the K-slice exchange of chain_epilogue
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int n0 = (blockIdx.x % p.tiles_x) * CBH, m0 = (blockIdx.x / p.tiles_x) * 32;
+    const int h = lane >> 5;
+    int row = m0 + (lane & 31);
+    row = row < p.M ? row : p.M - 1;  // clamped rows are computed, never stored
+    const float* pa = p.A + (long)row * p.lda;
+    const int col = n0 + (lane & 31);
+    f32x16 acc[NGATE];
+#pragma unroll
+    for (int i = 0; i < NGATE; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // K is walked EXACTLY as chain_kernel walks it, so that the two kernels give the same bits: steps of 64 k, wave kq
+    // the 16 k at 64 s + 16 kq of every step s; within them lane half h holds k + 8 c + 4 h + {0..3} (c = 0, 1) and MFMA
+    // (c, j) contracts the pair {8 c + j, 8 c + 4 + j}; a K with K % 64 == 32 ends in half a step (zeros in chain_kernel's
+    // LDS image, skipped here).
+    struct Frag { float4 a[2]; float4 w[NGATE][2]; };
+    const int nk = (p.K + 63) / 64;
+    auto load = [&](Frag& f, int st) {
+        const int k0 = 64 * st + 16 * kq;
+        const bool ok = st < nk && k0 < p.K;
+        const int k = (ok ? k0 : 0) + 4 * h;  // past the end: a valid address (K >= 32), the A half is zero
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f.a[c] = ok ? cld4(pa + k + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) {
+                if (!WKM) {
+                    f.w[i][c] = cld4(p.W + (long)(i * p.Hp + col) * p.ldw + k + 8 * c);
+                } else {
+                    const float* w = p.W + (long)(k + 8 * c) * p.ldw + col;
+                    f.w[i][c] = make_float4(w[0], w[p.ldw], w[2 * (long)p.ldw], w[3 * (long)p.ldw]);
+                }
+            }
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = CHAIN_MFMA(f.w[i][c].x, f.a[c].x, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = CHAIN_MFMA(f.w[i][c].y, f.a[c].y, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = CHAIN_MFMA(f.w[i][c].z, f.a[c].z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i) acc[i] = CHAIN_MFMA(f.w[i][c].w, f.a[c].w, acc[i]);
+        }
+    };
+    // two steps in flight ahead of the one being contracted
+    Frag f0, f1, f2;
+    load(f0, 0);
+    load(f1, 1);
+    for (int st = 0; st < nk; st += 3) {
+        load(f2, st + 2);
+        mma(f0);
+        if (st + 1 < nk) {
+            load(f0, st + 3);
+            mma(f1);
+        }
+        if (st + 2 < nk) {
+            load(f1, st + 4);
+            mma(f2);
+        }
+    }
+    if (kq == 0) chain_epilogue<NGATE, TAIL, KS, 0, false>(p, acc, lds, m0, n0, 0, lane);
+    else if (kq == 1) chain_epilogue<NGATE, TAIL, KS, 1, false>(p, acc, lds, m0, n0, 0, lane);
+    else if (kq == 2) chain_epilogue<NGATE, TAIL, KS, 2, false>(p, acc, lds, m0, n0, 0, lane);
+    else chain_epilogue<NGATE, TAIL, KS, 3, false>(p, acc, lds, m0, n0, 0, lane);
+}
+
+// rows up to which chain_small_kernel serves a level (DVAE_CHAIN_SMALL_M: 0 = never).  Measured on the train step
+// against GEMM + pointwise launches (cfg 1 / cfg 2 shapes, same box): B = 32 +10 %, 64 +9 %, 128 +1.5 %, 256 +-0.
+int chain_small_rows() {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_SMALL_M"); return v ? atoi(v) : 128; }();
+    return knob;
+}
+
 // ---------------------------------------------------------------------------------- persistent encoder chain
 // The whole forward chain of the encoder (models.py:675-685, both directions) as ONE launch.
 //
@@ -683,6 +774,13 @@ static int chain_launch(ChainBatch& b, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) {
         b.d[i].tiles_x = b.d[i].Hp / CBH;
         b.d[i].tiles_y = cdiv(b.d[i].M, CBM);
+    }
+    if (count == 1 && b.d[0].M <= chain_small_rows()) {
+        ChainParams& p = b.d[0];
+        p.tiles_y = cdiv(p.M, 32);
+        hipLaunchKernelGGL((chain_small_kernel<NGATE, WKM, TAIL>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, s, p);
+        DVAE_LAUNCH_CHECK();
+        return DVAE_OK;
     }
     // DVAE_CHAIN_KS = 2 / 4 forces the workgroup shape (A/B runs)
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_KS"); return v ? atoi(v) : 0; }();

@@ -132,6 +132,7 @@ int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, floa
 int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training,
                     const float* dz, const float* gk, float* dmu, float* dlogvar, int B, int nz, int NZp, hipStream_t s);
 
+int chain_small_rows();  // chain.hip: levels of at most this many rows run chain_small_kernel
 // chain.hip: the encoder's forward chain as one persistent launch (DVAE_CHAIN_PERSIST=1)
 constexpr int ENC_CHAIN_SYNC_WORDS = 2 * 256 * 32 + 64;  // [2 directions][<= 256 row tiles][32] counters, then the status word
 struct EncChainDir {

@@ -376,7 +376,7 @@ static bool chain_level_small(const Dims& d, int B) {
 }
 static bool chain_fused(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
-    return (knob == 2 || (knob == 1 && chain_level_small(d, B))) && !d.bf16 && !d.bn;
+    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows()))) && !d.bf16 && !d.bn;
 }
 // both encoder directions of a level as one grid (dvae_chain_level_batch) instead of two streams:
 // measured no faster forward (0.64 ms either way) and slower backward (1.08 -> 1.27 ms), because
@@ -401,7 +401,7 @@ static bool chain_merge_dirs() {
 // the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD=0 falls back
 static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
-    return (knob == 2 || (knob == 1 && chain_level_small(d, B))) && !d.bf16 && !d.bn;
+    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows()))) && !d.bf16 && !d.bn;
 }
 
 // The weight gradients of a backward chain (dWhh, d[Wg|Wm]) are sums over levels: each level's term is enqueued on a
