@@ -401,7 +401,8 @@ static bool chain_merge_dirs() {
 // the backward twins (dgrad + GRU backward tail, dgrad accumulate): DVAE_CHAIN_FUSED_BWD=0 falls back
 static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
-    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows()))) && !d.bf16 && !d.bn;
+    static const int small_bwd = [] { const char* v = getenv("DVAE_CHAIN_SMALL_M_BWD"); return v ? atoi(v) : 128; }();
+    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= (small_bwd < chain_small_rows() ? small_bwd : chain_small_rows())))) && !d.bf16 && !d.bn;
 }
 
 // The weight gradients of a backward chain (dWhh, d[Wg|Wm]) are sums over levels: each level's term is enqueued on a
