@@ -142,6 +142,7 @@ class DAGBatch(object):
         self.blob_host = host
         self.blob = None
         self.ready = None
+        self._used_on = set()  # streams the caching allocator has been told about (wait_ready)
         if on_gpu:
             # The copy runs on a copy stream of its own, so a batch packed ahead of time (harness prefetch thread)
             # does not queue behind the compute already enqueued; consumers wait on `ready` (wait_ready()).
@@ -153,7 +154,18 @@ class DAGBatch(object):
                     self.ready.record(cs)
 
     def wait_ready(self):
-        """orders the current stream behind the blob's host-to-device copy (until the copy is known to be done)"""
+        """Called by every consumer before it enqueues kernels that read the blob: orders the current stream behind
+        the blob's host-to-device copy (until the copy is known to be done), and tells the caching allocator that the
+        blob is in use on this stream.  The blob was allocated under the COPY stream: without `record_stream` its
+        memory goes back to that stream's pool the moment the batch object dies, and the next batch's copy may
+        overwrite it while kernels enqueued for this batch -- the host runs steps ahead of the GPU -- still read
+        their indices from it.  (The library's own side streams are joined into the caller's stream before each
+        call returns, so the caller's stream covers them.)"""
+        if self.blob is not None and self.blob.is_cuda:
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream not in self._used_on:
+                self.blob.record_stream(cur)
+                self._used_on.add(cur.cuda_stream)
         if self.ready is not None:
             if self.ready.query():
                 self.ready = None

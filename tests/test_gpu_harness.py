@@ -138,3 +138,36 @@ def test_optimizer_checkpoints_are_torch_adam_checkpoints(tmp_path):
         for k in want:
             moved = (want[k] - start[k]).norm().item()
             assert (got[k] - want[k]).norm().item() <= 2e-3 * moved + 1e-7, (first_flat, k, (got[k] - want[k]).abs().max().item())
+
+
+def test_batches_outlive_the_kernels_that_read_them():
+    """A packed batch's index blob is allocated under the copy stream; the kernels that read it run on the compute
+    stream, far behind the host at batch 32.  Dropping the batch object must not let the next batch's copy reuse the
+    memory early (DAGBatch.wait_ready -> record_stream).  The compute stream is first held back by ~100 ms of
+    unrelated work, then 40 forward passes run on batches that die as soon as they are enqueued; the sums must equal
+    those of the same passes with every batch kept alive."""
+    torch.manual_seed(0)
+    ga, _ = _dataset(40 * 32, 3)
+    model = dvae_amd.DVAE(8, 8, 0, 1, hs=64, nz=16, bidirectional=True).cuda().eval()
+    eps = torch.zeros(32, 16, device="cuda")
+    big = torch.randn(6144, 6144, device="cuda")
+
+    def run(keep):
+        held, tot = [], torch.zeros((), device="cuda", dtype=torch.float64)
+        torch.cuda.synchronize()
+        for _ in range(6):
+            big @ big  # the compute stream falls behind the host
+        with torch.no_grad():
+            for i in range(40):
+                b = model._collate_fn(ga[32 * i:32 * (i + 1)])
+                mu, logvar = model.encode(b)
+                loss, _, _ = model.loss(mu, logvar, b, eps=eps)
+                tot += loss.double()
+                assert torch.cuda.current_stream().cuda_stream in b._used_on
+                if keep:
+                    held.append(b)
+        torch.cuda.synchronize()
+        return tot.item()
+
+    kept, dropped = run(True), run(False)
+    assert np.isfinite(kept) and abs(kept - dropped) <= 1e-6 * abs(kept), (kept, dropped)
