@@ -120,89 +120,68 @@ from types import SimpleNamespace
 from .graph import DAG, IN as _IN
 
 
+def _one_graph(rows_to_arrays, row):
+    """a single row through the array codec above -> (DAG, n_vertices)"""
+    ga = rows_to_arrays([row])
+    n = int(ga.n_vertices[0])
+    return DAG.from_arrays(ga.types[0], ga.pred_mask[0], n), n
+
+
 def decode_ENAS_to_igraph(row):
-    """ENAS row -> (DAG, n_vertices); `util.py:128-144`.  Vertex ids are a topological order."""
-    row = parse_row(row)
-    n = len(row)
-    g = DAG()
-    g.add_vertices(n + 2)
-    g.vs[0]["type"] = 0
-    for i, node in enumerate(row):
-        g.vs[i + 1]["type"] = node[0] + 2
-        g.add_edge(i, i + 1)
-        for j, e in enumerate(node[1:]):
-            if e == 1:
-                g.add_edge(j, i + 1)
-    g.vs[n + 1]["type"] = 1
-    g.add_edge(n, n + 1)
-    return g, n + 2
+    """ENAS row -> (DAG, n_vertices), the interface of `util.py:128-144`; built by `enas_rows_to_arrays`
+    (vertex ids are a topological order)."""
+    return _one_graph(enas_rows_to_arrays, row)
 
 
 def decode_BN_to_igraph(row):
-    """Bayesian-network row -> (DAG, n_vertices); `util.py:255-275`."""
-    row = parse_row(row)
-    n = len(row)
-    g = DAG()
-    g.add_vertices(n + 2)
-    g.vs[0]["type"] = 0
-    for i, node in enumerate(row):
-        g.vs[i + 1]["type"] = node[0] + 2
-        if sum(node[1:]) == 0:
-            g.add_edge(0, i + 1)
-        else:
-            for j, e in enumerate(node[1:]):
-                if e == 1:
-                    g.add_edge(j + 1, i + 1)
-    g.vs[n + 1]["type"] = 1
-    for j in [v.index for v in g.vs.select(_outdegree_eq=0) if v.index != n + 1]:
-        g.add_edge(j, n + 1)
-    return g, n + 2
+    """Bayesian-network row -> (DAG, n_vertices), the interface of `util.py:255-275`; built by `bn_rows_to_arrays`."""
+    return _one_graph(bn_rows_to_arrays, row)
+
+
+def _masks(g):
+    """(types, predecessor bitmasks) of a DAG, vertex by vertex"""
+    types = [int(t) for t in g.vs["type"]]
+    masks = [sum(1 << u for u in preds) for preds in g.get_adjlist(_IN)]
+    return types, masks
 
 
 def flat_ENAS_to_nested(row, n_nodes):
-    """'4 0 1 3 1 0 ...' -> [[4], [0, 1], [3, 1, 0], ...]; `util.py:147-158`."""
-    if isinstance(row, str):
-        row = [int(x) for x in row.split()]
-    cnt, res = 0, []
-    for i in range(1, n_nodes + 1):
-        res.append(row[cnt:cnt + i])
-        cnt += i
-        if cnt == len(row):
+    """'4 0 1 3 1 0 ...' -> [[4], [0, 1], [3, 1, 0], ...] (layer i takes 1 + i numbers; `util.py:147-158`)."""
+    flat = [int(x) for x in row.split()] if isinstance(row, str) else list(row)
+    layers, pos = [], 0
+    for width in range(1, n_nodes + 1):
+        if pos >= len(flat):
             break
-    return res
+        layers.append(flat[pos:pos + width])
+        pos += width
+    return layers
 
 
 def decode_igraph_to_ENAS(g):
-    """graph -> flattened ENAS string (types - 2, optional-edge flags); `util.py:161-173`."""
-    n = g.vcount()
-    res = []
-    adjlist = g.get_adjlist(_IN)
-    for i in range(1, n - 1):
-        res.append(int(g.vs[i]["type"]) - 2)
-        row = [0] * (i - 1)
-        for j in adjlist[i]:
-            if j < i - 1:
-                row[j] = 1
-        res += row
-    return " ".join(str(x) for x in res)
+    """graph -> flattened ENAS string: per inner vertex v its type - 2, then one flag per vertex u < v - 1 (the edge
+    v - 1 -> v is implied); the inverse of `enas_rows_to_arrays` (`util.py:161-173`)."""
+    types, masks = _masks(g)
+    out = []
+    for v in range(1, len(types) - 1):
+        out.append(types[v] - 2)
+        out.extend((masks[v] >> u) & 1 for u in range(v - 1))
+    return " ".join(str(x) for x in out)
 
 
 def decode_igraph_to_BN_adj(g):
-    """BN graph -> flattened adjacency string in variable order; `util.py:278-284`."""
-    types = g.vs["type"][1:-1]
-    order = np.argsort(types).tolist()
-    adj = np.array(g.get_adjacency().data)[1:-1, 1:-1]
-    adj = adj[order][:, order]
-    return " ".join(str(x) for x in adj.reshape(-1))
+    """BN graph -> flattened variable-by-variable adjacency string, variables in the order of their ids (vertex
+    type - 2), entry [a][b] = edge a -> b (`util.py:278-284`)."""
+    types, masks = _masks(g)
+    inner = sorted(range(1, len(types) - 1), key=lambda v: types[v])  # stable: equal types keep vertex order
+    return " ".join(str((masks[b] >> a) & 1) for a in inner for b in inner)
 
 
 def adjstr_to_BN(row, n_vars=8):
-    """flattened adjacency string -> BN row format; `util.py:287-296`."""
-    matrix = np.array([int(x) for x in row.split()]).reshape(n_vars, n_vars)
-    res = [[0]]
-    for i in range(1, n_vars):
-        res.append([i] + matrix[:i, i].tolist())
-    return res
+    """flattened adjacency string -> BN row format: variable i with one flag per earlier variable (`util.py:287-296`)."""
+    bits = [int(x) for x in row.split()]
+    if len(bits) != n_vars * n_vars:
+        raise ValueError("expected %d adjacency entries, found %d" % (n_vars * n_vars, len(bits)))
+    return [[i] + [bits[j * n_vars + i] for j in range(i)] for i in range(n_vars)]
 
 
 def _load_rows(path, with_y, burn_in):
@@ -273,14 +252,7 @@ def load_BN_graphs(name, n_types=8, fmt="igraph", rand_seed=0, with_y=True, data
 # ---------------------------------------------------------------------------------------------
 def is_same_DAG(g0, g1):
     """same vertex types and predecessor sets, vertex by vertex (no isomorphism test)"""
-    if g0.vcount() != g1.vcount():
-        return False
-    for vi in range(g0.vcount()):
-        if g0.vs[vi]["type"] != g1.vs[vi]["type"]:
-            return False
-        if set(g0.neighbors(vi, "in")) != set(g1.neighbors(vi, "in")):
-            return False
-    return True
+    return g0.vcount() == g1.vcount() and _masks(g0) == _masks(g1)
 
 
 def ratio_same_DAG(G0, G1):
@@ -292,31 +264,32 @@ def ratio_same_DAG(G0, G1):
 
 
 def is_valid_DAG(g, START_TYPE=0, END_TYPE=1):
-    res = g.is_dag()
-    n_start, n_end = 0, 0
-    for v in g.vs:
-        if v["type"] == START_TYPE:
-            n_start += 1
-        elif v["type"] == END_TYPE:
-            n_end += 1
-        if v.indegree() == 0 and v["type"] != START_TYPE:
+    """acyclic, exactly one START and one END vertex, START the only vertex without predecessors and END the only
+    one without successors"""
+    types, masks = _masks(g)
+    has_succ = 0
+    for m in masks:
+        has_succ |= m
+    for v, t in enumerate(types):
+        if masks[v] == 0 and t != START_TYPE:
             return False
-        if v.outdegree() == 0 and v["type"] != END_TYPE:
+        if not (has_succ >> v) & 1 and t != END_TYPE:
             return False
-    return res and n_start == 1 and n_end == 1
+    return g.is_dag() and types.count(START_TYPE) == 1 and types.count(END_TYPE) == 1
 
 
 def is_valid_ENAS(g, START_TYPE=0, END_TYPE=1):
-    res = is_valid_DAG(g, START_TYPE, END_TYPE)
-    for i in range(g.vcount() - 2):
-        res = res and g.are_connected(i, i + 1)
-        if not res:
-            return res
-    return res and (g.vs[g.vcount() - 1].indegree() == 1)
+    """a valid DAG whose layers form a chain 0 -> 1 -> ... -> n-2 and whose output has that chain's end as its only
+    predecessor"""
+    if not is_valid_DAG(g, START_TYPE, END_TYPE):
+        return False
+    _, masks = _masks(g)
+    n = len(masks)
+    return all((masks[v + 1] >> v) & 1 for v in range(n - 2)) and bin(masks[n - 1]).count("1") == 1
 
 
 def is_valid_BN(g, START_TYPE=0, END_TYPE=1, nvt=10):
-    res = g.is_dag()
-    types = g.vs["type"]
-    res = res and types.count(START_TYPE) == 1 and types.count(END_TYPE) == 1
-    return res and len(set(types)) == nvt and g.vcount() == nvt
+    """acyclic, one START, one END, and every one of the nvt vertex types exactly once"""
+    types = [int(t) for t in g.vs["type"]]
+    return (g.is_dag() and types.count(START_TYPE) == 1 and types.count(END_TYPE) == 1 and
+            len(set(types)) == nvt and len(types) == nvt)
