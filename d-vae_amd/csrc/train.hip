@@ -890,7 +890,9 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     if (by_level) DVAE_TRY(join_side(side, s));
     DVAE_TRY(pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t, pw + L.be1,
                           pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, w.dw2_blocks, c->NP, HEp, w.sums, tickets,
-                          beta, out3, s, pair_group_knob() ? c->NP / c->B : 0));
+                          beta, out3, s, (pair_group_knob() && c->B >= w.dw2_blocks / 2) ? c->NP / c->B : 0));
+    // (whole graphs per workgroup only when there are graphs enough to fill the grid: at batch 32 that mapping left 32
+    // workgroups walking 28 pairs each, 63 us instead of ~12)
     // vertex-type predictor
     if (!by_level) {
         DVAE_TRY(dvae_gather_sum_f32(w.vs, Hp, w.st, Hp, bv.vs_off, bv.vs_idx, c->R, Hp, 0, s));
