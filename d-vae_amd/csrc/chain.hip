@@ -85,7 +85,8 @@ struct IC { static constexpr int value = V; };  // compile-time register-set ind
 // (The K loop has NO branch between its steps: with conditional loads hipcc's wait-count insertion
 // falls back to s_waitcnt vmcnt(0) before every LDS store, which drains all the tiles in flight.)
 // Diagnostic builds only (tools/chain_ablate.sh; results are wrong, only the time matters): CHAIN_ABL bit 0 drops the
-// pointwise tail (the K-slice exchange stays), bit 1 the MFMAs, bit 2 runs one K step instead of all.
+// pointwise tail (the K-slice exchange stays), bit 1 the MFMAs, bit 2 runs one K step instead of all, bit 3 drops the
+// GRU forward tail's gate / ghn stores (4 of its 5 output arrays).
 #ifndef CHAIN_ABL
 #define CHAIN_ABL 0
 #endif
@@ -118,10 +119,12 @@ __device__ __forceinline__ void gru_tail(const ChainParams& p, int row, int col,
     GRU1(x) GRU1(y) GRU1(z) GRU1(w)
 #undef GRU1
     float* g = p.gates + (long)row * 3 * p.Hp;
-    cst4(g + col, R);
-    cst4(g + p.Hp + col, Z);
-    cst4(g + 2 * p.Hp + col, N);
-    cst4(p.ghn + (long)row * p.Hp + col, GN);
+    if (!(CHAIN_ABL & 8)) {  // (diagnostic: bit 3 keeps only the state store; the values stay alive through Hn's inputs)
+        cst4(g + col, R);
+        cst4(g + p.Hp + col, Z);
+        cst4(g + 2 * p.Hp + col, N);
+        cst4(p.ghn + (long)row * p.Hp + col, GN);
+    }
     if (SC1) st4_sc1(rsrc_of(p.hout), (unsigned)((row * p.ld_hout + col) * 4), Hn);  // read by the row tile's other workgroups
     else cst4(p.hout + (long)row * p.ld_hout + col, Hn);
 }
