@@ -456,6 +456,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()  # rank 0 is still timing its roofline leg: the other ranks keep their communicators until it is done
         dist.destroy_process_group()
 
 
