@@ -40,13 +40,13 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     return __builtin_bit_cast(uint2, b);
 }
 
-template <int ROWS, bool KMAJOR, bool KGATHER>
+template <int ROWS, bool KMAJOR, bool KGATHER, int NT = 256>
 struct TileLoaderH {
-    static constexpr int UNITS = ROWS / 16;  // float4 units per thread: 2, 4 or 8
+    static constexpr int UNITS = ROWS * 16 / NT;  // float4 units per thread: 2, 4 or 8
     static constexpr int KM_LD = KmLd<ROWS>::value;
     static constexpr int LDS_ELEMS = KMAJOR ? BKH * KM_LD : ROWS * KC_LDH;  // bf16 elements
-    static constexpr int KROWS = 256 / (ROWS / 4);                          // K-major: k rows covered by one unit round
-    static_assert(UNITS == 2 || UNITS == 4 || UNITS == 8, "tile rows must be 32, 64 or 128");
+    static constexpr int KROWS = NT / (ROWS / 4);                           // K-major: k rows covered by one unit round
+    static_assert(UNITS == 2 || UNITS == 4 || UNITS == 8, "tile rows must be 32, 64 or 128 (256 threads), 256 (512 threads)");
 
     float4 r[UNITS];
     const float* rowp[UNITS];  // K-contig: start of the (gathered, clamped) row
@@ -63,7 +63,7 @@ struct TileLoaderH {
         if (!KMAJOR) {
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
-                int row = (tid + 256 * i) >> 4;
+                int row = (tid + NT * i) >> 4;
                 int rr = r0 + row;
                 rr = rr < rdim ? rr : rdim - 1;  // clamped rows are computed but never stored
                 long ridx = rows ? (long)rows[rr] : (long)rr;
@@ -112,7 +112,7 @@ struct TileLoaderH {
             const bool ok = k0 + c4 * 4 < kend;
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
-                int row = (tid + 256 * i) >> 4;
+                int row = (tid + NT * i) >> 4;
                 float4 v = ok ? r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<uint2*>(lds + row * KC_LDH + c4 * 4) = pack_bf16x4(v);
             }
@@ -149,26 +149,43 @@ __device__ __forceinline__ bf16x8 frag_h(const __bf16* lds, int roff, int s, int
 }
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(WM * WN == 4, "4 waves");
-    using LA = TileLoaderH<BM, AKM, false>;
-    using LB = TileLoaderH<BN, BKM, KGATHER>;
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NT = 64 * WM * WN;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+    using LA = TileLoaderH<BM, AKM, false, NT>;
+    using LB = TileLoaderH<BN, BKM, KGATHER, NT>;
     constexpr int STAGE = LA::LDS_ELEMS + LB::LDS_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int kbeg = 0, kend = p.K;
-    if (p.split_k > 1) {
+    constexpr bool XMAP = BM == 256;  // the 256 x 256 weight-gradient tile: one (K range, tile) item per workgroup, see launch
+    const int ntiles = p.tiles_x * p.tiles_y;  // persistent over output tiles, as in gemm.hip
+    int kbeg = 0, kend = p.K, first = blockIdx.x, stride = gridDim.x;
+    if (XMAP) {
+        // Items are numbered K range by K range and dealt to the XCDs in contiguous runs (workgroup ids equal
+        // mod 8 share an XCD and its L2), so the tiles that contract one K range -- and re-read the same rows of
+        // both operands, N/256 and M/256 times -- meet in one L2 and HBM delivers each operand about once.
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int ks = id / ntiles;
+        first = id - ks * ntiles;
+        stride = ntiles;  // one tile per workgroup
+        kbeg = ks * p.k_per_split;
+        kend = min(p.K, kbeg + p.k_per_split);
+    } else if (p.split_k > 1) {
         kbeg = blockIdx.z * p.k_per_split;
         kend = min(p.K, kbeg + p.k_per_split);
         if (kbeg >= kend) return;
     }
-    const int ntiles = p.tiles_x * p.tiles_y;  // persistent over output tiles, as in gemm.hip
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    for (int tl = first; tl < ntiles; tl += stride) {
     int m0, n0;
-    tile_origin<BM, BN>(tl, p.tiles_x, ntiles, m0, n0);
+    if (XMAP) {
+        m0 = (tl % p.tiles_y) * BM;
+        n0 = (tl / p.tiles_y) * BN;
+    } else {
+        tile_origin<BM, BN>(tl, p.tiles_x, ntiles, m0, n0);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -237,7 +254,11 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
     const long ntiles = (long)p.tiles_x * p.tiles_y;
     const long cap = (BM * BN >= 128 * 128 ? 512 : 1024);
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, p.split_k > 1 ? p.split_k : 1);
-    dim3 block(256);
+    if (BM == 256) {  // one workgroup per (K range, tile)
+        if (p.split_k < 1 || p.k_per_split <= 0) { p.split_k = 1; p.k_per_split = cdiv(p.K, BKH) * BKH; }
+        grid = dim3((unsigned)(ntiles * p.split_k), 1, 1);
+    }
+    dim3 block(64 * WM * WN);
     const bool kg = bkm && p.b_rows != nullptr;
     if (akm && p.a_rows) return set_err(DVAE_ERR_ARG, "gemm: row gather on a K-major A operand is not built");
 #define DVAE_GEMM_LAUNCH(A_, B_, G_)                                                                              \
@@ -246,6 +267,11 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_, B_, G_, false>), grid, block, 0, s, p);     \
     } while (0)
     const bool vec = gemm_vec_epilogue_ok(p);
+    if constexpr (BM == 256) {  // built for the weight-gradient form only
+        if (!(akm && bkm)) return set_err(DVAE_ERR_ARG, "gemm: the 256 x 256 tile is built for two K-major operands");
+        if (kg) DVAE_GEMM_LAUNCH(true, true, true);
+        else DVAE_GEMM_LAUNCH(true, true, false);
+    } else
     if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
     else if (!akm && bkm && !kg) DVAE_GEMM_LAUNCH(false, true, false);
     else if (akm && bkm && !kg) DVAE_GEMM_LAUNCH(true, true, false);
@@ -285,11 +311,38 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     // workgroups (two or more per CU) over long K loops.
     static const int knob_tile = getenv("DVAE_GEMM_TILE") ? atoi(getenv("DVAE_GEMM_TILE")) : 0;    // tools/gemm_tune.py
     static const int knob_split = getenv("DVAE_GEMM_SPLIT") ? atoi(getenv("DVAE_GEMM_SPLIT")) : 0;
+    static const int knob_log = getenv("DVAE_GEMM_LOG") ? atoi(getenv("DVAE_GEMM_LOG")) : 0;
     long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
     long t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
     bool use128 = t128 >= 384 || (d.a_kmajor && t128 >= 64);
     int ksteps = cdiv(d.K, BKH);
     bool small_m = d.M <= 32 && d.a_kmajor;
+    // Large weight gradients (cfg 5: 4096 x 1024 and 3072 x 1024 outputs contracted over 1e5 .. 6e5 rows): 256 x 256
+    // tiles halve the operand bytes each MFMA flop pulls through L2 -> LDS, which is what bounds these products
+    // (fp32-stored operands, 8 bytes per element pair); the K ranges fill the chip, one workgroup per CU.
+    const bool can_split = d.accumulate && d.bias == nullptr && d.act == 0;
+    const long t256 = (long)cdiv(d.M, 256) * cdiv(d.N, 256);
+    bool use256 = d.a_kmajor && d.b_kmajor && can_split && t256 >= 16 && ksteps >= 256 && d.a_rows == nullptr;
+    static const int knob_256 = getenv("DVAE_WGRAD_256") ? atoi(getenv("DVAE_WGRAD_256")) : 1;  // 0: the 128 x 128 tile as before
+    if (!knob_256) use256 = false;
+    if (knob_tile == 256) use256 = d.a_kmajor && d.b_kmajor && d.a_rows == nullptr;
+    else if (knob_tile) use256 = false;
+    if (use256) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        int sk = can_split ? (int)(cus / t256) : 1;
+        if (sk > ksteps / 8) sk = ksteps / 8;
+        if (knob_split > 0 && can_split) sk = knob_split < ksteps ? knob_split : ksteps;
+        if (sk < 1) sk = 1;
+        p.k_per_split = cdiv(ksteps, sk) * BKH;
+        p.split_k = cdiv(d.K, p.k_per_split);
+        if (knob_log)
+            fprintf(stderr, "GEMMSELH 256x256 %d %d %d akm=1 bkm=1 split=%d br=%d\n", d.M, d.N, d.K, p.split_k, d.b_rows != nullptr);
+        return launch_cfg_h<256, 256, 2, 4>(p, d.a_kmajor, d.b_kmajor, s);
+    }
     if (knob_tile == 128) { use128 = true; small_m = false; }
     else if (knob_tile == 64) { use128 = false; small_m = false; }
     else if (knob_tile == 32) small_m = true;
@@ -315,6 +368,9 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
             p.split_k = cdiv(d.K, p.k_per_split);
         }
     }
+    if (knob_log)
+        fprintf(stderr, "GEMMSELH %s %d %d %d akm=%d bkm=%d split=%d br=%d\n", small_m ? "32x128" : use128 ? "128x128" : "64x64", d.M,
+                d.N, d.K, d.a_kmajor, d.b_kmajor, p.split_k, d.b_rows != nullptr);
     if (small_m) return launch_cfg_h<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
     if (use128) return launch_cfg_h<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
     return launch_cfg_h<64, 64, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);

@@ -235,6 +235,10 @@ int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
     // (split-K for accumulating products was built and measured on cfg 5's level data gradients, 2048 x 1024 x 3072 /
     // 2048, fp32 x bf16: 64 x 64 tiles unsplit 32.6 / 23.8 us; split 2 / 3 / 4: 37.7 / 43.3 / 47.9 us; 128 x 128 tiles
     // 49.9 unsplit, 45.8 at best -- the atomics on an 8 MB output cost more than the shorter K loop saves.  Not kept.)
+    static const int knob_log = getenv("DVAE_GEMM_LOG") ? atoi(getenv("DVAE_GEMM_LOG")) : 0;
+    if (knob_log)
+        fprintf(stderr, "GEMMSELN %s %d %d %d abf=%d bbf=%d ar=%d acc=%d\n", big ? "256x256" : mid ? "128x128" : "64x64", d.M, d.N, d.K,
+                d.a_bf16, d.b_bf16, d.a_rows != nullptr, d.accumulate);
     if (big) return launch_nn<256, 256, 2, 4>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
     if (mid) return launch_nn<128, 128, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);
     return launch_nn<64, 64, 2, 2>(p, d.a_bf16 != 0, d.b_bf16 != 0, cus, s);

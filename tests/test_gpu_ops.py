@@ -589,8 +589,11 @@ def test_gemm_bf16_dgrad_kmajor_b(M, N, K):
     assert (out - ref).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize("rows,N,K", [(8192, 1536, 512), (333, 64, 32), (5000, 32, 1536), (70, 128, 512), (9251, 2048, 512)])
+@pytest.mark.parametrize("rows,N,K", [(8192, 1536, 512), (333, 64, 32), (5000, 32, 1536), (70, 128, 512), (9251, 2048, 512),
+                                      (16421, 1000, 1000), (20000, 2048, 1024)])
 def test_gemm_bf16_wgrad_splitk(rows, N, K):
+    """the last two shapes (>= 16 tiles of 256 x 256, >= 256 K steps) take the 8-wave 256 x 256 weight-gradient tile
+    with its XCD-major (K range, tile) workgroup order; ragged M / N / K edges on the first of them"""
     g = torch.Generator(device="cuda").manual_seed(rows)
     dY = torch.randn(rows, N, device="cuda", generator=g)
     X = torch.randn(rows + 50, K, device="cuda", generator=g)
