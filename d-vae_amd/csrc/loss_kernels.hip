@@ -192,15 +192,27 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
     const int n_groups = group > 0 ? (n_pairs + group - 1) / group : 0;
     const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, j = blockIdx.x >> 3;
     const bool coop = group > 0 && (gridDim.x & 7) == 0 && J > 0;
-    const int per_graph = coop ? (group + J - 1) / J : group;  // iterations a workgroup spends on one graph
+    // ... in runs of RUN consecutive pairs: the pairs (v, u = 0, 1, ...) of a vertex v read the SAME EB row until u
+    // passes a predecessor of v (~9 pairs per row at cfg 5), so a workgroup that walks consecutive pairs keeps the row
+    // in registers and reads one table row per pair instead of two (132 -> ~80 GB of L2 reads per pass).
+    constexpr int RUN = 16;
+    const int per_graph = coop ? ((group + RUN - 1) / RUN + J - 1) / J * RUN : group;  // iterations a workgroup spends on one graph
     const int iters = coop ? ((n_groups + 7) / 8) * per_graph
                            : group > 0 ? ((n_groups + gridDim.x - 1) / gridDim.x) * group : (n_pairs + gridDim.x - 1) / gridDim.x;
     uint16_t* mask16 = reinterpret_cast<uint16_t*>(mask);
-    int executed = 0;
-    for (int it = 0; it < iters; ++it) {
+    int executed = 0, held = -1;  // held: the EB row in `bq`
+    float4 bq[NITW], b1q[NITW], w2q[NITW];  // this wave's quarter of the EB row, of b1 and of w2
+#pragma unroll
+    for (int ii = 0; ii < NITW; ++ii) {
+        const int c = lane * 4 + 256 * (wave * NITW + ii);
+        b1q[ii] = c < HEp ? ld4c(b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        w2q[ii] = c < HEp ? ld4c(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto pair_of = [&](int it) -> int {  // the pair of iteration `it`, n_pairs when there is none (uniform over the workgroup)
+        if (it >= iters) return n_pairs;
         int p;
         if (coop) {
-            const int run = xcd + 8 * (it / per_graph), k = j + J * (it % per_graph);
+            const int run = xcd + 8 * (it / per_graph), w = it % per_graph, k = (j + J * (w / RUN)) * RUN + w % RUN;
             p = (run < n_groups && k < group) ? run * group + k : n_pairs;
         } else if (group > 0) {
             const int run = blockIdx.x + (it / group) * gridDim.x;
@@ -208,10 +220,42 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
         } else {
             p = blockIdx.x + it * gridDim.x;
         }
-        if (p >= n_pairs) continue;  // uniform over the workgroup
+        return p < n_pairs ? p : n_pairs;
+    };
+    // The rows of the NEXT pair are requested as soon as the current pair's have been consumed, into the same
+    // registers: their latency (and that of the index loads in front of them) then runs under the current pair's
+    // reduction, barrier and loss arithmetic instead of in front of the next pair's (the kernel was bound by that
+    // chain -- 3.4 us per pair and workgroup -- not by bytes: halving its L2 reads alone changed nothing).
+    float4 aq[NITW];
+    auto fetch = [&](int p) {
         const float* ra = ea + (long)pair_a[p] * HEp;
-        const float* rb = eb + (long)pair_h[p] * HEp;
+#pragma unroll
+        for (int ii = 0; ii < NITW; ++ii) {
+            const int c = lane * 4 + 256 * (wave * NITW + ii);
+            aq[ii] = c < HEp ? ld4c(ra + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int hrow = pair_h[p];
+        if (hrow != held) {  // uniform over the workgroup
+            const float* rb = eb + (long)hrow * HEp;
+#pragma unroll
+            for (int ii = 0; ii < NITW; ++ii) {
+                const int c = lane * 4 + 256 * (wave * NITW + ii);
+                bq[ii] = c < HEp ? ld4c(rb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            held = hrow;
+        }
+    };
+    int p = pair_of(0);
+    if (p < n_pairs) fetch(p);
+    for (int it = 0; it < iters; ++it) {
+        const int pn = pair_of(it + 1);
+        if (p >= n_pairs) {  // uniform over the workgroup
+            if (pn < n_pairs) fetch(pn);
+            p = pn;
+            continue;
+        }
         const float* rc = ec ? ec + (long)pair_c[p] * HEp : nullptr;
+        const float t = (float)pair_t[p];
         float rv[NITW * 4];
         uint32_t bits16 = 0u;
         float s = 0.f;
@@ -220,7 +264,7 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
             const int c = lane * 4 + 256 * (wave * NITW + ii);
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < HEp) {
-                float4 a = ld4c(ra + c), b = ld4c(rb + c), bb = ld4c(b1 + c), w = ld4c(w2 + c);
+                float4 a = aq[ii], b = bq[ii], bb = b1q[ii], w = w2q[ii];
                 float4 pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
                 if (rc) {
                     float4 cc = ld4c(rc + c);
@@ -234,13 +278,13 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
             }
             rv[4 * ii + 0] = r.x; rv[4 * ii + 1] = r.y; rv[4 * ii + 2] = r.z; rv[4 * ii + 3] = r.w;
         }
+        if (pn < n_pairs) fetch(pn);  // aq / bq are free again
         s = wave_sum(s);
         float* slot = xch + 4 * (executed++ & 1);  // (parity of the pairs actually run: skipped iterations take no barrier)
         if (lane == 0) slot[wave] = s;
         __syncthreads();  // (the slots of pair it - 1 are free again: every wave passed this barrier after reading them)
         s = slot[0] + slot[1] + slot[2] + slot[3] + bias2;  // the same order in every wave
         float prob = 1.f / (1.f + expf(-s));
-        float t = (float)pair_t[p];
         float lp = fmaxf(logf(prob), -100.f);
         float lq = fmaxf(logf(1.f - prob), -100.f);
         float pq = prob * (1.f - prob);
@@ -255,6 +299,7 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < NITW * 4; ++i) aw[i] += g * rv[i];
         }
+        p = pn;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
