@@ -44,7 +44,7 @@ class LevelDesc(C.Structure):
                                           "msg", "next_agg", "next_off", "idx", "dx", "hprev", "dgh", "dgin", "dhprev",
                                           "gather_src", "gather_src2", "off2", "idx2", "dgm_next")] + \
                [(n, C.c_int32) for n in ("lda", "K", "ld_hout", "ld_msg", "cur_row0", "ld_agg", "ld_dx", "ld_hprev",
-                                         "ld_dhprev")]
+                                         "ld_dhprev", "ldw_bf16")] + [("w_bf16", C.c_void_p)]
 
 
 _P = C.c_void_p

@@ -736,6 +736,204 @@ int enc_chain_fwd(const EncChainArgs& a, hipStream_t s) {
     return DVAE_OK;
 }
 
+// ---------------------------------------------------------------------------------- bf16 levels
+// The same four level operations with bf16 matrix-unit inputs (dvae_model_desc.mfma_bf16) for LARGE levels (cfg 5:
+// 2048 rows, Hp = 1024), where the unfused form -- a product that writes the [rows x 3Hp] pre-activations, then a
+// pointwise kernel that reads them back -- is two launches of 25-55 us each per operation and the 64-level chains were a
+// third of the step.  v_mfma_f32_32x32x16_bf16, fp32 accumulation, the fp32 tails above unchanged.
+//   workgroup: 128 rows x 64 hidden units x all NGATE gates, 8 waves = (K half) x (row half) x (hidden half): a wave
+//              contracts two of the four 16-k groups of every 64-k step for two 32-row blocks x NGATE gates (GRU: 6
+//              accumulators, 5 fragment reads per 6 MFMAs), two waves per SIMD; the K halves meet through LDS in the
+//              epilogue (chain_epilogue, KS = 2), which also halves the tails a wave runs one after the other;
+//   operands:  A fp32 [rows][K] (states / gradients), rounded to bf16 on the way from registers to LDS, exactly as the
+//              bf16 GEMMs round it; W the K-contiguous bf16 copy of the weight (pack.hip: straight for the forward
+//              operations, transposed for the backward ones), so all four are products of two K-contiguous operands;
+//   pipeline:  two LDS stages of [128 + 64 NGATE][64 + 8] bf16 and TWO register-staged tiles in flight (fixed register
+//              sets, the loop unrolled by two: no rotation moves at the back-edge); scheduling barriers keep the
+//              fp32 -> bf16 conversion of a staged tile where it is written, or hipcc hoists it -- and the wait for
+//              the loads with it -- to the top of the step (measured: 1.3 us per K step, every load latency exposed);
+//   tile order: gemm_common.h's XCD-aware order (an XCD's 32 tiles = 8 row tiles x 4 hidden tiles share its L2).
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HBM_ROWS = 128, HBH = 64, HBK = 64, HLD = HBK + 8;
+
+template <int NGATE>
+struct ChainBf16Lds {
+    static constexpr int A_ELEMS = HBM_ROWS * HLD, STAGE = A_ELEMS + NGATE * HBH * HLD;  // bf16 elements
+    static constexpr int XCH_BYTES = 4 * 8 * NGATE * 64 * 16;  // 4 (hidden half, row block) regions of chain_epilogue<KS = 2>
+    static constexpr int BYTES = 2 * STAGE * 2 > XCH_BYTES ? 2 * STAGE * 2 : XCH_BYTES;
+};
+
+template <int NGATE, int TAIL>
+__global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const uint16_t* __restrict__ Wh, int ldwh) {
+    using LD = ChainBf16Lds<NGATE>;
+    constexpr int A_ELEMS = LD::A_ELEMS, STAGE = LD::STAGE;
+    constexpr int AU = HBM_ROWS * HBK / 4 / 512;    // float4 units of A per thread (4)
+    constexpr int BU = NGATE * HBH * HBK / 8 / 512;  // 16-byte units of W per thread (one per gate)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LD::BYTES];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, h = lane >> 5;
+    int m0, n0;
+    tile_origin<HBM_ROWS, HBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
+
+    f32x16 acc[2][NGATE];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < NGATE; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][i][r] = 0.f;
+
+    // staging: thread -> (row, 4 k) of A, (row, 8 k) of W; rows past M are clamped (computed, never stored)
+    const float* arow[AU];
+    const uint16_t* wrow[BU];
+    const int ac4 = tid & 15, wc8 = tid & 7;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+        int r = m0 + ((tid + 512 * i) >> 4);
+        r = r < p.M ? r : p.M - 1;
+        arow[i] = p.A + (long)r * p.lda + ac4 * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BU; ++i) {
+        const int r = (tid + 512 * i) >> 3;  // 0 .. 64 NGATE - 1: gate r / 64, hidden unit n0 + r % 64
+        wrow[i] = Wh + (long)((r / HBH) * p.Hp + n0 + r % HBH) * ldwh + wc8 * 8;
+    }
+    float4 ra[2][AU];
+    u32x4 rw[2][BU];  // (a native vector: hipcc keeps HIP's uint4 struct array in memory -- promoted to LDS -- and waits for every load at once)
+    const int nk = (CHAIN_ABL & 4) ? 1 : p.K / HBK;
+    auto gload = [&](auto set, int t) {
+        constexpr int S = decltype(set)::value;
+        const int k = (t < nk ? t : 0) * HBK;  // past the end: a valid tile, loaded and never used
+#pragma unroll
+        for (int i = 0; i < AU; ++i) ra[S][i] = cld4(arow[i] + k);
+#pragma unroll
+        for (int i = 0; i < BU; ++i) rw[S][i] = *reinterpret_cast<const u32x4*>(wrow[i] + k);
+    };
+    auto lstore = [&](auto set, __bf16* st) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const cbf16x4 b = {(__bf16)ra[S][i].x, (__bf16)ra[S][i].y, (__bf16)ra[S][i].z, (__bf16)ra[S][i].w};
+            *reinterpret_cast<uint2*>(st + ((tid + 512 * i) >> 4) * HLD + ac4 * 4) = __builtin_bit_cast(uint2, b);
+        }
+#pragma unroll
+        for (int i = 0; i < BU; ++i)
+            *reinterpret_cast<u32x4*>(st + A_ELEMS + ((tid + 512 * i) >> 3) * HLD + wc8 * 8) = rw[S][i];
+    };
+    // step t contracts LDS stage t & 1; in its middle the staged tile t + 1 (register set (t + 1) & 1, requested two
+    // steps ago) goes to the other stage and the set is refilled with tile t + 3
+    auto step = [&](auto nset, int t) {
+        constexpr int NS = decltype(nset)::value;  // (t + 1) & 1
+        const __bf16* a_l = lds + (NS ^ 1) * STAGE;
+        const __bf16* b_l = a_l + A_ELEMS;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kc = (2 * (2 * kq + s2) + h) * 8;  // this wave's 16-k group 2 kq + s2 of the step, lane half h
+            cbf16x8 af[2], bf[NGATE];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                af[rb] = *reinterpret_cast<const cbf16x8*>(a_l + (wm * 64 + rb * 32 + (lane & 31)) * HLD + kc);
+#pragma unroll
+            for (int i = 0; i < NGATE; ++i)
+                bf[i] = *reinterpret_cast<const cbf16x8*>(b_l + (i * HBH + wn * 32 + (lane & 31)) * HLD + kc);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int i = 0; i < NGATE; ++i)  // operands swapped: a lane holds 4 consecutive hidden units of one row per quad
+                    if (!(CHAIN_ABL & 2)) acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[i], af[rb], acc[rb][i], 0, 0, 0);
+                    else acc[rb][i][0] += (float)bf[i][0] * (float)af[rb][0];  // (diagnostic: keeps the fragment reads alive)
+            if (s2 == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                lstore(nset, lds + NS * STAGE);
+                __builtin_amdgcn_sched_barrier(0);
+                gload(nset, t + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+    gload(IC<0>{}, 0);
+    lstore(IC<0>{}, lds);
+    gload(IC<1>{}, 1);
+    gload(IC<0>{}, 2);
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        step(IC<1>{}, t);
+        step(IC<0>{}, t + 1);
+    }
+    if (t < nk) step(IC<1>{}, t);
+    // the K halves meet in chain_epilogue: one exchange region per (hidden half, row block)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        float* region = reinterpret_cast<float*>(lds_raw) + (wn * 2 + rb) * (8 * NGATE * 64 * 4);
+        const int mb = m0 + wm * 32 + rb * 32;  // chain_epilogue adds wm * 32: rows m0 + wm * 64 + rb * 32 ..
+        if (kq == 0) chain_epilogue<NGATE, TAIL, 2, 0, false>(p, acc[rb], region, mb, n0 + wn * 32, wm, lane);
+        else chain_epilogue<NGATE, TAIL, 2, 1, false>(p, acc[rb], region, mb, n0 + wn * 32, wm, lane);
+    }
+}
+
+// Levels the bf16 kernels may serve inside the train step: whole 64-wide hidden tiles and 64-deep K steps, and enough
+// 128 x 64 tiles to fill three quarters of the chip (cfg 5: 16 x 16 = 256 tiles).  OFF by default (DVAE_CHAIN_BF16=1
+// turns them on, =2 also lifts the size rule); a descriptor that carries w_bf16 runs them regardless.
+// MEASURED (cfg 5 level, 2048 rows, Hp 1024, tools/chain_bf16_bench.py; us alone, product + pointwise launches -> this
+// kernel): GRU forward 45.2 -> 41.3, gate forward 34.9 -> 32.1, dgrad + GRU backward 38.7 -> 52.8, dgrad accumulate +
+// gather tail 31.3 + ~35 -> 40.8.  Ablation (tools/chain_ablate.sh): the K loops are 19 / 15 / 19 / 28 us, the tails 22 /
+// 17 / 34 / 12 us -- a level's outputs (75-100 MB: gates, W_hn h, states, gradients of all of them) move at 3-3.4 TB/s
+// while the CU's matrix unit idles, one 512-thread workgroup (98 KB of LDS) per CU.  In the step the two encoder
+// directions run on two streams, and the unfused pair overlaps one direction's pointwise kernel with the other's
+// product; the fused kernels cannot share a CU: cfg 5 bf16 step 101.1 ms unfused, 109.1 ms with these kernels, 113.1 ms
+// with both directions of a level on one stream.  Kept for the numbers and for callers with one chain; not the default.
+bool chain_bf16_ok(int rows, int Hp) {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_BF16"); return v ? atoi(v) : 0; }();
+    if (!knob || Hp % HBH != 0 || rows < 1) return false;
+    return knob == 2 || (long)cdiv(rows, HBM_ROWS) * (Hp / HBH) >= 192;
+}
+
+// The packed weights of the bf16-mode call in progress on this thread (set by the orchestration's entry points, orch.h:
+// set_mode): dvae_chain_level_batch looks a level's fp32 weight up in it and runs the bf16 kernel on the copy.
+static thread_local const float* tl_chain_pw = nullptr;
+static thread_local PackedLayout tl_chain_layout;
+void chain_bf16_context(const float* pw, const PackedLayout* L) {
+    tl_chain_pw = pw;
+    if (pw && L) tl_chain_layout = *L;
+}
+// -> the K-contiguous bf16 copy of weight `w` (forward: as stored, pitch Hp; backward: the transposed copy, pitch =
+// the matrix' rows), or NULL when the context does not hold it
+static const uint16_t* chain_bf16_lookup(const float* w, bool backward, int Hp, int K, int ngate, int* ldw) {
+    const PackedLayout& L = tl_chain_layout;
+    if (!tl_chain_pw || w < tl_chain_pw || w >= tl_chain_pw + L.total) return nullptr;
+    const size_t off = (size_t)(w - tl_chain_pw);
+    if (!backward) {
+        if (off % 8) return nullptr;
+        *ldw = Hp;
+        return reinterpret_cast<const uint16_t*>(tl_chain_pw + L.half) + off;
+    }
+    for (int i = 0; i < L.nmats; ++i) {
+        const PackedLayout::Mat& m = L.mats[i];
+        if (off != m.off) continue;  // the backward operations contract a whole matrix [K][Hp]
+        if (m.rows != K || m.cols != Hp || m.toff % 8) return nullptr;
+        *ldw = m.rows;
+        return reinterpret_cast<const uint16_t*>(tl_chain_pw + L.halfT) + m.toff;
+    }
+    return nullptr;
+}
+
+template <int NGATE, int TAIL>
+static int chain_bf16_launch(ChainParams p, const uint16_t* wh, int ldwh, hipStream_t s) {
+    DVAE_REQUIRE(p.Hp % HBH == 0 && p.K % HBK == 0 && p.K >= HBK, "bf16 chain level: Hp and K must be multiples of 64 (Hp=%d K=%d)", p.Hp, p.K);
+    DVAE_REQUIRE(wh && ((uintptr_t)wh % 16) == 0 && ldwh % 8 == 0 && ldwh >= p.K, "bf16 chain level: the bf16 weight needs 16-byte aligned rows of at least K elements");
+    p.tiles_x = p.Hp / HBH;
+    p.tiles_y = cdiv(p.M, HBM_ROWS);
+    static const int knob_log = [] { const char* v = getenv("DVAE_GEMM_LOG"); return v ? atoi(v) : 0; }();
+    if (knob_log) fprintf(stderr, "CHAINSEL chain_bf16_kernel<%d, %d> %d %d %d\n", NGATE, TAIL, p.M, NGATE * p.Hp, p.K);
+    hipLaunchKernelGGL((chain_bf16_kernel<NGATE, TAIL>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(512), 0, s, p, wh, ldwh);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+
 // ---------------------------------------------------------------------------------- host
 template <int NGATE, bool WKM, int TAIL, int KS, int ND>
 static int chain_launch_ks(ChainBatch& b, hipStream_t s) {
@@ -863,6 +1061,32 @@ extern "C" int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels,
     if (count == 1) b.d[1] = b.d[0];
     DVAE_REQUIRE(b.d[1].K == b.d[0].K, "chain level batch: the levels of a launch share K");
     hipStream_t s = (hipStream_t)stream;
+    {   // bf16 matrix-unit inputs: an explicit bf16 weight in the descriptor, or the bf16-mode call in progress holds one
+        const bool backward = op == DVAE_LEVEL_DGRAD_ACC || op == DVAE_LEVEL_GRU_BWD;
+        const uint16_t* wh[2] = {nullptr, nullptr};
+        int ldwh[2] = {0, 0};
+        bool all = true, any_explicit = false;
+        for (int i = 0; i < count; ++i) {
+            if (levels[i].w_bf16) {
+                wh[i] = levels[i].w_bf16; ldwh[i] = levels[i].ldw_bf16; any_explicit = true;
+            } else if (chain_bf16_ok(rows, Hp) && b.d[i].K % HBK == 0) {
+                wh[i] = chain_bf16_lookup(levels[i].w, backward, Hp, b.d[i].K, 0, &ldwh[i]);
+            }
+            all = all && wh[i] != nullptr;
+        }
+        DVAE_REQUIRE(all || !any_explicit, "chain level batch: w_bf16 must be given for every level of the launch or none");
+        if (all) {
+            for (int i = 0; i < count; ++i) {
+                switch (op) {
+                case DVAE_LEVEL_GRU_FWD: DVAE_TRY((chain_bf16_launch<3, 0>(b.d[i], wh[i], ldwh[i], s))); break;
+                case DVAE_LEVEL_GATED_FWD: DVAE_TRY((chain_bf16_launch<2, 1>(b.d[i], wh[i], ldwh[i], s))); break;
+                case DVAE_LEVEL_DGRAD_ACC: DVAE_TRY((chain_bf16_launch<1, 2>(b.d[i], wh[i], ldwh[i], s))); break;
+                default: DVAE_TRY((chain_bf16_launch<1, 3>(b.d[i], wh[i], ldwh[i], s))); break;
+                }
+            }
+            return DVAE_OK;
+        }
+    }
     switch (op) {
     case DVAE_LEVEL_GRU_FWD: return chain_launch<3, false, 0>(b, count, s);
     case DVAE_LEVEL_GATED_FWD: return chain_launch<2, false, 1>(b, count, s);

@@ -18,6 +18,7 @@ static inline void set_mode(const Dims& d, const PackedLayout& L, const float* p
     tl_bf16 = d.bf16;
     tl_pw = d.bf16 ? pw : nullptr;
     if (d.bf16) tl_layout = L;
+    chain_bf16_context(d.bf16 ? pw : nullptr, &L);  // the fused level kernels find their bf16 weight copies through it
 }
 // A product whose B operand is a packed weight matrix reads the bf16 copy instead (half the bytes, no conversion in the
 // K loop), and a data gradient (B K-major = the weight as stored) reads the TRANSPOSED bf16 copy, which makes it a

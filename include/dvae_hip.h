@@ -200,6 +200,12 @@ typedef struct dvae_level_desc {
     const int32_t* idx2;
     float* dgm_next;
     int32_t lda, K, ld_hout, ld_msg, cur_row0, ld_agg, ld_dx, ld_hprev, ld_dhprev;
+    /* bf16 matrix-unit inputs (optional; NULL = the exact-fp32 kernels): a K-CONTIGUOUS bf16 copy of the weight, row
+     * pitch ldw_bf16 elements -- the forward operations' [NGATE * Hp][Hp] as stored, the backward operations' weight
+     * TRANSPOSED, [Hp][K] -- for the bf16 level kernels (`a` rounded to bf16 on its way to the matrix unit, fp32
+     * accumulation and tails).  Needs Hp % 64 == 0 and K % 64 == 0; one level per launch. */
+    int32_t ldw_bf16;
+    const uint16_t* w_bf16;
 } dvae_level_desc;
 int dvae_chain_level_batch(int32_t op, const dvae_level_desc* levels, int32_t count, int32_t rows, int32_t Hp,
                            void* stream);
