@@ -392,7 +392,26 @@ __global__ __launch_bounds__(256) void pair_bwd_split_kernel(const int* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const int k1 = chunk_off[q + 1];
-        for (int k = chunk_off[q]; k < k1; ++k) {
+        int k = chunk_off[q];
+        // four pairs at a time: their index, gradient and mask loads are independent and go out together (one pair per
+        // trip left every trip waiting for its own three dependent loads: 3.63 -> 2.67 ms per pass at cfg 5; eight: 2.63)
+        for (; k + 3 < k1; k += 4) {
+            int pp[4];
+            float gg[4];
+            uint32_t mm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pp[u] = grp_pairs ? grp_pairs[k + u] : k + u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gg[u] = dl[pp[u]] * sc;
+                mm[u] = mask16[(((long)pp[u] * NW + (w >> 1)) * 64 + lane) * 2 + (w & 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += sel(mm[u], i, gg[u]);
+        }
+        for (; k < k1; ++k) {
             const int p = grp_pairs ? grp_pairs[k] : k;
             const float g = dl[p] * sc;
             const uint32_t mw = mask16[(((long)p * NW + (w >> 1)) * 64 + lane) * 2 + (w & 1)];
