@@ -25,3 +25,9 @@ timeout -k 10 200 python tools/host_cost.py cfg1 10 > $O/host_cost_cfg1.txt 2>&1
 for st in f32xf32 f32xbf16 bf16xbf16; do
   DVAE_GEMM_BF16=1 DVAE_GEMM_STORE=$st timeout -k 10 100 python tools/gemm_bench.py > $O/gemm_shapes_bf16_$st.txt 2>&1 || exit 1
 done
+# 4. cfg 5 in bf16 mode (round 2: large weight gradients, wide pair tables, bf16 level kernels)
+timeout -k 10 200 python tools/wgrad_bench.py > $O/wgrad_bf16_256.txt 2>&1 || exit 1
+DVAE_WGRAD_256=0 timeout -k 10 200 python tools/wgrad_bench.py > $O/wgrad_bf16_128.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/chain_bf16_bench.py > $O/chain_bf16_levels.txt 2>&1 || exit 1
+bash tools/kstats.sh cfg5_bf16 --config cfg5 --dtype bf16 --steps 3 --warmup 1 > $O/kstats_cfg5_bf16.txt 2>&1 || exit 1
+cp $R/gpurun_out/kstats/cfg5_bf16/s_kernel_stats.csv $O/cfg5_bf16_kernel_stats.csv || exit 1
