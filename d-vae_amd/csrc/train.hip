@@ -416,6 +416,14 @@ static bool chain_fused_bwd(const Dims& d, int B) {
 // delay the level kernels they share CUs with), so the default is the decoder only.  Capping the terms' split-K at 1
 // (fewer workgroups, no atomics) and a low-priority side stream were measured too: 4.16 ms and no change.
 // DVAE_WGRAD_BY_LEVEL: bit 0 decoder, bit 1 encoder (default 1; 0 = whole-pass products after the chains).
+// workgroups of the pair forward (= rows of its w2-gradient partials, summed by the backward): one pair per wave for
+// small batches instead of the full 1024 (batch 32: 896 pairs; every workgroup clears its LDS, writes HEp partial sums
+// and draws a ticket whether it has a pair or not), whole multiples of 8 for the per-XCD graph mapping
+static int pair_blocks(int n_pairs, int cap) {
+    int nb = ((n_pairs + 3) / 4 + 7) & ~7;
+    if (nb < 64) nb = 64;
+    return nb < cap ? nb : cap;
+}
 static int pair_group_knob() {
     static const int knob = [] { const char* v = getenv("DVAE_PAIR_GROUP"); return v ? atoi(v) : 1; }();
     return knob;
@@ -877,7 +885,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     }
     // The loss terms meet through tickets (loss_kernels.hip: loss_ticket): the pair kernel's and the CE kernel's
     // workgroups each draw one, the last writes out3 -- so the vertex-type predictor's tail can run on the side stream.
-    const unsigned tickets = (unsigned)(w.dw2_blocks + vertex_ce_blocks(c->R));
+    const int nblk = pair_blocks(c->NP, w.dw2_blocks);
+    const unsigned tickets = (unsigned)(nblk + vertex_ce_blocks(c->R));
     auto vertex_tail = [&](hipStream_t st) -> int {
         // (the Tp-wide logits product stays one launch: a level's slice of it is 16 workgroups)
         DVAE_TRY(lin_fwd(w.v1, d.HVp, nullptr, pw + L.wv2, d.HVp, pw + L.bv2, w.logits, d.Tp, c->R, d.Tp, d.HVp, 0, 0, st));
@@ -891,7 +900,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
     if (by_level) DVAE_TRY(join_side(side, s));
     DVAE_TRY(pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t, pw + L.be1,
-                          pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, w.dw2_blocks, c->NP, HEp, w.sums, tickets,
+                          pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, nblk, c->NP, HEp, w.sums, tickets,
                           beta, out3, s, (pair_group_knob() && c->B >= w.dw2_blocks / 2) ? c->NP / c->B : 0));
     // (whole graphs per workgroup only when there are graphs enough to fill the grid: at batch 32 that mapping left 32
     // workgroups walking 28 pairs each, 63 us instead of ~12)
@@ -956,7 +965,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         // rows sorted by vertex type (off at xoh[0..T], idx from xoh[40]) for the GRU's input-side gradients, which
         // run on this stream at the end: a one-workgroup kernel bound by latency, kept off the main stream
         DVAE_TRY(dvae_type_csr(bv.types, nB, bv.p_type, PT, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s2));
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, w.dw2_blocks, w.dw2_blocks, HEp, s2));
+        const int nblk = pair_blocks(c->NP, w.dw2_blocks);  // as the forward launched them
+        DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, nblk, nblk, HEp, s2));
         DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
