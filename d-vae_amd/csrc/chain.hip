@@ -591,6 +591,106 @@ __global__ __launch_bounds__(256) void chain_small_kernel(ChainParams p) {
     else chain_epilogue<NGATE, TAIL, KS, 3, false>(p, acc, lds, m0, n0, 0, lane);
 }
 
+// The same once more for the FEWEST rows (batch 32, the reference's recipe): chain_small_kernel's 32 x 32 tiles give only
+// Hp / 32 = 16 workgroups there, each with 5.1 us of MFMA issue (a quarter of K x all gates per wave at one SIMD's fp32
+// rate) inside a 12-13 us launch.  v_mfma_f32_16x16x4_f32 tiles -- 16 rows x 16 hidden units x all gates per workgroup,
+// 4 waves = 4 interleaved K slices -- make it (Hp / 16) x ceil(rows / 16) = 64 workgroups with a quarter of that work
+// each.  Lane (i = lane % 16, kg = lane / 16) loads 4 consecutive k of row i of each operand at 16 s + 4 kg; MFMA j of a
+// step contracts k = 16 s + 4 kg + j over kg.  The K order differs from chain_kernel's (results agree to rounding, not
+// bit for bit).  The four slice sums meet in LDS in slice order; wave 0 runs the 64 (row, 4 hidden units) tails.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NGATE, bool WKM, int TAIL>
+__global__ __launch_bounds__(256) void chain_tiny_kernel(ChainParams p) {
+    __shared__ float4 xch[4][NGATE][64];
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int n0 = (blockIdx.x % p.tiles_x) * 16, m0 = (blockIdx.x / p.tiles_x) * 16;
+    const int li = lane & 15, kg = lane >> 4;
+    int row = m0 + li;
+    row = row < p.M ? row : p.M - 1;  // clamped rows are computed, never stored
+    const float* pa = p.A + (long)row * p.lda;
+    const int col = n0 + li;
+    f32x4v acc[NGATE];
+#pragma unroll
+    for (int i = 0; i < NGATE; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    struct Frag { float4 a; float4 w[NGATE]; };
+    const int ns = p.K / 16;  // 16-k steps; wave kq takes steps kq, kq + 4, ...
+    auto load = [&](Frag& f, int st) {
+        const bool ok = st < ns;
+        const int k = (ok ? 16 * st : 0) + 4 * kg;  // past the end: a valid address, the A part is zero
+        f.a = ok ? cld4(pa + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NGATE; ++i) {
+            if (!WKM) {
+                f.w[i] = cld4(p.W + (long)(i * p.Hp + col) * p.ldw + k);
+            } else {
+                const float* w = p.W + (long)k * p.ldw + col;
+                f.w[i] = make_float4(w[0], w[p.ldw], w[2 * (long)p.ldw], w[3 * (long)p.ldw]);
+            }
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < NGATE; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[i].x, f.a.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[i].y, f.a.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[i].z, f.a.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[i].w, f.a.w, acc[i], 0, 0, 0);
+        }
+    };
+    // two steps in flight ahead of the one being contracted (fixed register sets, as chain_small_kernel)
+    Frag f0, f1, f2;
+    load(f0, kq);
+    load(f1, kq + 4);
+    for (int st = kq; st < ns; st += 12) {
+        load(f2, st + 8);
+        mma(f0);
+        if (st + 4 < ns) {
+            load(f0, st + 12);
+            mma(f1);
+        }
+        if (st + 8 < ns) {
+            load(f1, st + 16);
+            mma(f2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NGATE; ++i) xch[kq][i][lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    __syncthreads();
+    if (kq != 0) return;
+    const int orow = m0 + li;
+    if (orow >= p.M) return;
+    float4 v[NGATE];
+#pragma unroll
+    for (int i = 0; i < NGATE; ++i) {
+        float4 sum = xch[0][i][lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {  // K slices in order
+            const float4 t = xch[k][i][lane];
+            sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+        }
+        v[i] = sum;
+    }
+    const int ocol = n0 + 4 * kg;  // D[i = 4 kg + r][j = li]: 4 consecutive hidden units of row li
+    if (TAIL == 0) {
+        gru_tail<false>(p, orow, ocol, v[0], v[NGATE > 1 ? 1 : 0], v[NGATE - 1]);
+    } else if (TAIL == 1) {
+        gate_tail<false>(p, orow, ocol, v[0], v[NGATE - 1]);
+    } else {
+        float* c = p.C + (long)orow * p.ldc + ocol;
+        const float4 c0 = cld4(c);
+        const float4 d = make_float4(c0.x + v[0].x, c0.y + v[0].y, c0.z + v[0].z, c0.w + v[0].w);
+        cst4(c, d);
+        if (TAIL == 3) gru_bwd_tail(p, orow, ocol, d);
+        if (TAIL == 2 && p.dgm_out) gather_bwd_tail(p, orow, ocol, d);
+    }
+}
+
+// rows up to which chain_tiny_kernel serves a level (DVAE_CHAIN_TINY_M: 0 = never)
+int chain_tiny_rows() {
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_TINY_M"); return v ? atoi(v) : 32; }();
+    return knob;
+}
+
 // rows up to which chain_small_kernel serves a level (DVAE_CHAIN_SMALL_M: 0 = never).  Measured on the train step
 // against GEMM + pointwise launches (cfg 1 / cfg 2 shapes, same box): B = 32 +10 %, 64 +9 %, 128 +1.5 %, 256 +-0.
 int chain_small_rows() {
@@ -975,6 +1075,14 @@ static int chain_launch(ChainBatch& b, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) {
         b.d[i].tiles_x = b.d[i].Hp / CBH;
         b.d[i].tiles_y = cdiv(b.d[i].M, CBM);
+    }
+    if (count == 1 && b.d[0].M <= chain_tiny_rows() && b.d[0].M <= chain_small_rows()) {
+        ChainParams& p = b.d[0];
+        p.tiles_x = p.Hp / 16;
+        p.tiles_y = cdiv(p.M, 16);
+        hipLaunchKernelGGL((chain_tiny_kernel<NGATE, WKM, TAIL>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0, s, p);
+        DVAE_LAUNCH_CHECK();
+        return DVAE_OK;
     }
     if (count == 1 && b.d[0].M <= chain_small_rows()) {
         ChainParams& p = b.d[0];

@@ -133,6 +133,7 @@ int reparam_kld_bwd(const float* mu, const float* logvar, const float* eps, floa
                     const float* dz, const float* gk, float* dmu, float* dlogvar, int B, int nz, int NZp, hipStream_t s);
 
 int chain_small_rows();  // chain.hip: levels of at most this many rows run chain_small_kernel
+int chain_tiny_rows();   // chain.hip: levels of at most this many rows run chain_tiny_kernel (16 x 16 tiles)
 bool chain_bf16_ok(int rows, int Hp);  // chain.hip: does the bf16 level kernel serve levels of this shape?
 void chain_bf16_context(const float* pw, const PackedLayout* L);  // chain.hip: the bf16-mode call in progress (NULL: none)
 // chain.hip: the encoder's forward chain as one persistent launch (DVAE_CHAIN_PERSIST=1)

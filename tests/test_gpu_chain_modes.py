@@ -3,7 +3,8 @@ BASELINE cfg 2 / cfg 4), so the small parity cases of test_gpu_parity.py run the
 launches instead.  Here the same parity cases (reference golden vectors, oracle on random / ragged /
 64-vertex batches) are re-run in a child process with the fused kernels FORCED for every level size,
 in each of their modes: 8-wave workgroups, 4-wave workgroups, both encoder directions in one grid, the
-encoder's forward chain as one persistent launch, and the 32-row kernels of small levels (forced for every size).
+encoder's forward chain as one persistent launch, the 32-row kernels of small levels and the 16-row kernels of the
+smallest (each forced for every size).
 (The knobs are read once per process, hence the child process; one at a time, GPU use stays at 2 processes.)"""
 import os
 import subprocess
@@ -22,8 +23,10 @@ BIG = {"DVAE_CHAIN_SMALL_M": "0"}  # the test batches are small: keep them off c
 
 
 @pytest.mark.parametrize("extra", [BIG, dict(BIG, DVAE_CHAIN_KS="2"), dict(BIG, DVAE_CHAIN_MERGE="1"),
-                                   dict(BIG, DVAE_CHAIN_PERSIST="1"), {"DVAE_CHAIN_SMALL_M": "4096"}],
-                         ids=["8-wave", "4-wave", "merged-directions", "persistent-encoder", "small-level-kernels"])
+                                   dict(BIG, DVAE_CHAIN_PERSIST="1"), {"DVAE_CHAIN_SMALL_M": "4096", "DVAE_CHAIN_TINY_M": "0"},
+                                   {"DVAE_CHAIN_SMALL_M": "4096", "DVAE_CHAIN_TINY_M": "4096"}],
+                         ids=["8-wave", "4-wave", "merged-directions", "persistent-encoder", "small-level-kernels",
+                              "tiny-level-kernels"])
 def test_parity_with_fused_level_kernels_forced(extra):
     env = dict(os.environ, **FORCED, **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
