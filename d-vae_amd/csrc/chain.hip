@@ -685,9 +685,11 @@ __global__ __launch_bounds__(256) void chain_tiny_kernel(ChainParams p) {
     }
 }
 
-// rows up to which chain_tiny_kernel serves a level (DVAE_CHAIN_TINY_M: 0 = never)
+// rows up to which chain_tiny_kernel serves a level (DVAE_CHAIN_TINY_M: 0 = never).  Measured on the train step (cfg 1
+// model, same box, against chain_small_kernel / product + pointwise launches): B = 32 +17 %, 64 +20 %, 128 +17 %, 256 +15 %,
+// 512 +-0 (2048 workgroups that re-read their operands from L2: the 64-row LDS-tiled kernels take over from there).
 int chain_tiny_rows() {
-    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_TINY_M"); return v ? atoi(v) : 32; }();
+    static const int knob = [] { const char* v = getenv("DVAE_CHAIN_TINY_M"); return v ? atoi(v) : 256; }();
     return knob;
 }
 
@@ -1076,7 +1078,7 @@ static int chain_launch(ChainBatch& b, int count, hipStream_t s) {
         b.d[i].tiles_x = b.d[i].Hp / CBH;
         b.d[i].tiles_y = cdiv(b.d[i].M, CBM);
     }
-    if (count == 1 && b.d[0].M <= chain_tiny_rows() && b.d[0].M <= chain_small_rows()) {
+    if (count == 1 && b.d[0].M <= chain_tiny_rows()) {
         ChainParams& p = b.d[0];
         p.tiles_x = p.Hp / 16;
         p.tiles_y = cdiv(p.M, 16);

@@ -377,7 +377,7 @@ static bool chain_level_small(const Dims& d, int B) {
 static bool chain_fused(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
     if (d.bf16) return knob != 0 && !d.bn && chain_bf16_ok(B, d.Hp);  // the bf16 level kernels (chain.hip): large levels only
-    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows()))) && !d.bn;
+    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows() || B <= chain_tiny_rows()))) && !d.bn;
 }
 // both encoder directions of a level as one grid (dvae_chain_level_batch) instead of two streams:
 // measured no faster forward (0.64 ms either way) and slower backward (1.08 -> 1.27 ms), because
@@ -404,7 +404,8 @@ static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
     static const int small_bwd = [] { const char* v = getenv("DVAE_CHAIN_SMALL_M_BWD"); return v ? atoi(v) : 128; }();
     if (d.bf16) return knob != 0 && !d.bn && chain_bf16_ok(B, d.Hp);
-    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= (small_bwd < chain_small_rows() ? small_bwd : chain_small_rows())))) && !d.bn;
+    return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= (small_bwd < chain_small_rows() ? small_bwd : chain_small_rows()) ||
+                                        B <= chain_tiny_rows()))) && !d.bn;
 }
 
 // The weight gradients of a backward chain (dWhh, d[Wg|Wm]) are sums over levels: each level's term is enqueued on a

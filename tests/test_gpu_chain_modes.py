@@ -19,7 +19,8 @@ CASES = ("tiny_matches_reference_golden or random_graphs_match_oracle or max_siz
          "or (hs501_matches_reference_golden and cfg4)")
 
 
-BIG = {"DVAE_CHAIN_SMALL_M": "0"}  # the test batches are small: keep them off chain_small_kernel for the 64-row kernels' modes
+# the test batches are small: keep them off chain_small_kernel / chain_tiny_kernel for the 64-row kernels' modes
+BIG = {"DVAE_CHAIN_SMALL_M": "0", "DVAE_CHAIN_TINY_M": "0"}
 
 
 @pytest.mark.parametrize("extra", [BIG, dict(BIG, DVAE_CHAIN_KS="2"), dict(BIG, DVAE_CHAIN_MERGE="1"),

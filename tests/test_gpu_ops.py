@@ -734,9 +734,10 @@ def test_gru_level_bwd_fused_matches_dgrad_plus_pointwise(rows, Hp):
 
 def test_chain_level_batch_two_levels_equals_two_launches():
     """dvae_chain_level_batch with count = 2 (both encoder directions of a level in one grid) gives,
-    bit for bit, what two single-level launches give (same kernel, same summation order)."""
+    bit for bit, what two single-level launches give (same kernel, same summation order: more rows than the
+    16-row and 32-row kernels of small levels take, which walk K in another order)."""
     g = torch.Generator().manual_seed(77)
-    rows, Hp, T = 200, 64, 8
+    rows, Hp, T = 300, 64, 8
     lib = L.load()
 
     def mk():
