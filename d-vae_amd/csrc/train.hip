@@ -805,7 +805,11 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // level-major batches (every graph full size: all of the reference's data sets) run the
     // per-level predictor products beside the chain
     static const int by_level_knob = [] { const char* v = getenv("DVAE_BY_LEVEL"); return v ? atoi(v) : 1; }();
-    const bool by_level = !d.bn && c->level_major != 0 && by_level_knob != 0;
+    // (small batches: the per-level side-stream launches cost more host time -- a fork and three launches per level --
+    // than their overlap gains, and batch 32 is bound by the host's enqueue rate; measured on the step, by level vs whole
+    // batch: B = 32 26.2 k vs 29.9 k DAGs/s, 128 93.3 k vs 98.2 k, 256 149.6 k vs 152.2 k, 512 200.4 k vs 197.3 k;
+    // DVAE_BY_LEVEL=2 forces the per-level form at every size)
+    const bool by_level = !d.bn && c->level_major != 0 && (by_level_knob == 2 || (by_level_knob == 1 && c->B > 256));
     Side* side = nullptr;
     SideGuard side_guard{side, s};
     if (by_level) DVAE_TRY(side_for_stream(s, &side));

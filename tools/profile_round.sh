@@ -31,3 +31,7 @@ DVAE_WGRAD_256=0 timeout -k 10 200 python tools/wgrad_bench.py > $O/wgrad_bf16_1
 timeout -k 10 200 python tools/chain_bf16_bench.py > $O/chain_bf16_levels.txt 2>&1 || exit 1
 bash tools/kstats.sh cfg5_bf16 --config cfg5 --dtype bf16 --steps 3 --warmup 1 > $O/kstats_cfg5_bf16.txt 2>&1 || exit 1
 cp $R/gpurun_out/kstats/cfg5_bf16/s_kernel_stats.csv $O/cfg5_bf16_kernel_stats.csv || exit 1
+# 5. whole epochs including shuffling and packing (tools/epoch_bench.py)
+timeout -k 10 200 python tools/epoch_bench.py 17118 32 cfg1 > $O/epoch_b32_cfg1.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/epoch_bench.py 17118 32 cfg2 > $O/epoch_b32_cfg2.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/epoch_bench.py 17118 1024 cfg2 > $O/epoch_b1024_cfg2.txt 2>&1 || exit 1
