@@ -370,9 +370,11 @@ extern "C" int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batc
 // small tiles spread the work (same-box sweep of cfg 2 at B = 64 / 128 / 256 / 512: -7 / -8 / -5 / 0 %),
 // and a larger level (cfg 5: 2048 rows x Hp 1024 = 4 rounds) is a well-shaped product for the
 // 128 x 128 tiles of gemm.hip, whose operand reuse then wins (6.08 k vs 5.93 k DAGs/s).
+// (round 2, cfg 2 model at B = 384 / 512 / 768, fused vs product + pointwise: 153.1 k vs 156.0 k, 185.7 k vs 183.2 k,
+// 226.3 k vs 203.5 k DAGs/s: from half a round of the chip on; up to 256 rows chain_tiny_kernel serves the level.)
 static bool chain_level_small(const Dims& d, int B) {
     const long tiles = (long)cdiv(B, 64) * (d.Hp / 32);
-    return tiles >= 256 && tiles <= 512;
+    return tiles >= 128 && tiles <= 512;
 }
 static bool chain_fused(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
