@@ -438,7 +438,13 @@ static int wbl_knob() {
 static bool wgrad_by_level(int which = 1) { return (wbl_knob() & which) != 0; }
 // (bf16 mode, large levels -- cfg 5: 2048 rows x Hp 1024 -- the whole-pass products measured 1 % better; bit 2 of the
 // knob keeps the per-level terms there too)
-static bool wbl_size_ok(const Dims& d, int B) { return !d.bf16 || (long)B * d.Hp <= 1024L * 512 || (wbl_knob() & 4) != 0; }
+// (and not below 65 graphs: the per-level terms are 15 more launches and 7 forks per cfg 1 step, whose host time bounds
+// the batch-32 step -- 1.04 -> 0.99 ms, host enqueue 1.05 -> 0.85 ms; at 128 / 256 graphs they win by 0.5 %; bit 3 of the
+// knob keeps them at every batch size)
+static bool wbl_size_ok(const Dims& d, int B) {
+    if (B <= 64 && (wbl_knob() & 8) == 0) return false;
+    return !d.bf16 || (long)B * d.Hp <= 1024L * 512 || (wbl_knob() & 4) != 0;
+}
 static int wbl_split() {
     static const int knob = [] { const char* v = getenv("DVAE_WBL_SPLIT"); return v ? atoi(v) : 0; }();
     return knob;
