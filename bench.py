@@ -393,10 +393,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    launches0 = dvae_amd._lib.load().dvae_debug_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i, True)
     host_dt = time.perf_counter() - t0  # host time to ENQUEUE the steps (the GPU runs behind it)
+    launches = (dvae_amd._lib.load().dvae_debug_launch_count() - launches0) / float(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -435,6 +437,7 @@ def main():
                        "collective_backend": backend if world > 1 else "none",
                        "allreduce_ms_per_step": ar_ms,
                        "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                       "launches_per_step": launches,  # the library's kernel launches (its memsets / copies and torch's own are not counted)
                        "loss_last_step": loss_global},
             "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["achieved"] / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "dvae_encode_ws_floats": (C.c_int64, [_MD, _BC]),
     "dvae_loss_ws_floats": (C.c_int64, [_MD, _BC]),
     "dvae_debug_side_stream": (_I, [_P, C.POINTER(_P)]),
+    "dvae_debug_launch_count": (C.c_int64, []),
     "dvae_encode_forward": (_I, [_MD, _BC, _P, _P, _P, _P, _P, _P]),
     "dvae_encode_backward": (_I, [_MD, _BC, _P, _P, _P, _P, _P, _P, _P]),
     "dvae_loss_forward": (_I, [_MD, _BC, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),

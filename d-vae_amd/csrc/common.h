@@ -10,6 +10,7 @@ namespace dvae {
 // thread-local last-error text, returned by dvae_last_error()
 char* err_buf();
 int set_err(int code, const char* fmt, ...);
+void count_launch();  // api.cpp: kernel launches of this process (dvae_debug_launch_count)
 
 #define DVAE_OK 0
 #define DVAE_ERR_ARG -1
@@ -31,6 +32,7 @@ int set_err(int code, const char* fmt, ...);
 
 #define DVAE_LAUNCH_CHECK()                                                              \
     do {                                                                                 \
+        ::dvae::count_launch();                                                          \
         hipError_t e__ = hipGetLastError();                                              \
         if (e__ != hipSuccess)                                                           \
             return ::dvae::set_err(DVAE_ERR_HIP, "kernel launch failed: %s (%s:%d)",     \

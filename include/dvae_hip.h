@@ -352,6 +352,10 @@ int64_t dvae_loss_ws_floats(const dvae_model_desc* m, const dvae_batch_counts* c
  * workspace belongs to one call at a time.  dvae_debug_side_stream reports the side stream the library pairs
  * with a caller stream on the current device (diagnostics / tests; no counterpart in the reference). */
 int dvae_debug_side_stream(void* caller_stream, void** side_stream);
+/* Kernel launches the library has enqueued in this process so far (all threads, all devices; its memsets and copies
+ * are not counted).  Diagnostics: bench.py reports the difference over a step as config.launches_per_step; no
+ * counterpart in the reference. */
+int64_t dvae_debug_launch_count(void);
 
 /* DVAE.encode, models.py:720-731 (DVAE_BN.encode :1068-1080): mu, logvar [B][nz] */
 int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_counts* c, const int32_t* blob, const float* pw,
