@@ -378,7 +378,10 @@ static bool chain_level_small(const Dims& d, int B) {
 }
 static bool chain_fused(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED"); return v ? atoi(v) : 1; }();
-    if (d.bf16) return knob != 0 && !d.bn && chain_bf16_ok(B, d.Hp);  // the bf16 level kernels (chain.hip): large levels only
+    // bf16 mode: the bf16 level kernels (chain.hip) for large levels when enabled; the smallest levels run the exact-fp32
+    // chain_tiny_kernel in this mode too (bf16 inputs are a permission, not an obligation: at <= 256 rows the level is
+    // bound by launch and load latencies, not by the matrix unit -- cfg 1 bf16 25.4 k -> fp32-mode speed)
+    if (d.bf16) return knob != 0 && !d.bn && (chain_bf16_ok(B, d.Hp) || B <= chain_tiny_rows());
     return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= chain_small_rows() || B <= chain_tiny_rows()))) && !d.bn;
 }
 // both encoder directions of a level as one grid (dvae_chain_level_batch) instead of two streams:
@@ -405,7 +408,7 @@ static bool chain_merge_dirs() {
 static bool chain_fused_bwd(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_FUSED_BWD"); return v ? atoi(v) : 1; }();
     static const int small_bwd = [] { const char* v = getenv("DVAE_CHAIN_SMALL_M_BWD"); return v ? atoi(v) : 128; }();
-    if (d.bf16) return knob != 0 && !d.bn && chain_bf16_ok(B, d.Hp);
+    if (d.bf16) return knob != 0 && !d.bn && (chain_bf16_ok(B, d.Hp) || B <= chain_tiny_rows());
     return (knob == 2 || (knob == 1 && (chain_level_small(d, B) || B <= (small_bwd < chain_small_rows() ? small_bwd : chain_small_rows()) ||
                                         B <= chain_tiny_rows()))) && !d.bn;
 }
