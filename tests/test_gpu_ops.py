@@ -929,3 +929,20 @@ def test_side_streams_are_per_caller_stream_and_concurrent_calls_are_independent
         assert torch.equal(conc[i][1], serial[i][1])  # forward results are bit-reproducible
         for a, b in zip(conc[i][2], serial[i][2]):
             assert (a - b).abs().max() <= 1e-5 * b.abs().max()  # split-K sums arrive in any order
+
+
+def test_launch_counter_counts_library_launches():
+    """dvae_debug_launch_count (bench.py's config.launches_per_step): one product = one launch, a level
+    operation = one launch; it never goes backwards."""
+    lib = L.load()
+    A = torch.randn(64, 64, device="cuda")
+    W = torch.randn(64, 64, device="cuda")
+    out = torch.zeros(64, 64, device="cuda")
+    n0 = lib.dvae_debug_launch_count()
+    _gemm(A, W, out, 64, 64, 64)
+    n1 = lib.dvae_debug_launch_count()
+    assert n1 == n0 + 1
+    dx = torch.zeros(64, 64, device="cuda")
+    L.check(lib.dvae_level_dgrad_acc(A.data_ptr(), 64, 64, W.data_ptr(), dx.data_ptr(), 64, 64, 64, _s()))
+    torch.cuda.synchronize()
+    assert lib.dvae_debug_launch_count() == n1 + 1
