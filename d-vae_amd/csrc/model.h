@@ -152,4 +152,31 @@ struct EncChainArgs {
 };
 int enc_chain_fwd(const EncChainArgs& a, hipStream_t s);
 
+// chain_persist.hip: a whole pass (encoder direction(s) or the decoder chain, forward or backward) of a SMALL batch
+// as one persistent launch of 16 x 16 tiles
+constexpr int TINY_CHAIN_SYNC_WORDS = 2 * 16 * 32 + 64;  // [2 passes][<= 16 row tiles][32] counters, then the status word
+struct TinyChainDir {
+    // arrays of the forward pass, [n * B rows], level-major
+    float *agg, *gates, *ghn, *hs, *gm, *msg;
+    const float *whh, *wgm, *gi, *bhn, *gv;
+    const int *off, *idx;    // CSR over slots of a level's source slots (predecessors; the encoder's backward direction: successors)
+    // arrays of the backward pass
+    float *dhs, *dgm, *dgh, *dgin, *dagg;
+    const int *toff, *tidx;  // the transposed lists: the consumers of a slot's message
+    const float* gsrc2; const int *off2, *idx2;  // decoder: d agg of the partial rows and slot -> partial rows (else NULL)
+    int reverse;             // 1: the pass walks the vertices n-1 .. 0 (the encoder's backward direction)
+    int level0_product;      // 1: the pass's first level has a non-zero h_prev (the decoder's H0)
+};
+struct TinyChainArgs {
+    TinyChainDir d[2];
+    const int* types;
+    int B, Hp, n, ndirs;
+    unsigned* sync;    // TINY_CHAIN_SYNC_WORDS words; zeroed by the launcher
+    unsigned* status;  // == sync + TINY_CHAIN_SYNC_WORDS - 64; != 0 after the launch: a wait timed out
+    float* poison;     // nullable: receives + NaN when a wait times out
+};
+bool tiny_chain_fits(int B, int Hp, int passes);
+int tiny_chain_fwd(const TinyChainArgs& a, hipStream_t s);
+int tiny_chain_bwd(const TinyChainArgs& a, hipStream_t s);
+
 }  // namespace dvae

@@ -260,6 +260,7 @@ struct DecWs {
     uint32_t* mask;  // ReLU masks of the edge predictor, one bit per (pair, hidden unit)
     // backward
     float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dgm, *dh0c, *dz, *gs;
+    float* sync;  // counters of the persistent small-batch chain (chain_persist.hip), used as unsigned storage
     int dw2_blocks;
     size_t total;
 };
@@ -302,6 +303,7 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dh0c = d.bn ? b.take((size_t)c.B * Hp) : nullptr;
     w.dz = b.take((size_t)c.B * d.NZp);
     w.gs = b.take(8);
+    w.sync = b.take(TINY_CHAIN_SYNC_WORDS);
     w.total = b.off;
     return w;
 }
@@ -399,6 +401,18 @@ static bool chain_persist(const Dims& d, int B) {
     if (!knob || d.bf16 || d.bn) return false;
     const long tiles = (long)cdiv(B, 64) * (d.Hp / 32);
     return tiles <= 256 && tiles <= device_cu_count();
+}
+// Small batches (<= 256 rows per level): a whole pass as ONE persistent launch of 16 x 16 tiles (chain_persist.hip)
+// instead of two launches per level; DVAE_CHAIN_TINY_PERSIST=0 restores the per-level launches.
+static bool chain_tiny_persist(const Dims& d, int B, int passes = 1) {
+    return !d.bn && B <= chain_tiny_rows() && tiny_chain_fits(B, d.Hp, passes);
+}
+static void tiny_dir_fwd(TinyChainDir& e, float* agg, float* gates, float* ghn, float* hs, float* gm, float* msg,
+                         const float* whh, const float* wgm, const float* gi, const float* bhn, const float* gv,
+                         const int* off, const int* idx, int reverse, int level0_product) {
+    e.agg = agg; e.gates = gates; e.ghn = ghn; e.hs = hs; e.gm = gm; e.msg = msg;
+    e.whh = whh; e.wgm = wgm; e.gi = gi; e.bhn = bhn; e.gv = gv; e.off = off; e.idx = idx;
+    e.reverse = reverse; e.level0_product = level0_product;
 }
 static bool chain_merge_dirs() {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_MERGE"); return v ? atoi(v) : 0; }();
@@ -522,7 +536,8 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     // host is still issuing the other one's launches.
     // (optional, DVAE_CHAIN_MERGE=1: both directions of a level as ONE grid on the caller's stream,
     // dvae_chain_level_batch, instead of two streams)
-    const bool persist = chain_persist(d, c->B);
+    const bool tiny = fused && chain_tiny_persist(d, c->B, dirs);
+    const bool persist = tiny || chain_persist(d, c->B);
     const bool merged = !persist && fused && dirs == 2 && !d.bn && chain_merge_dirs();
     Side* side = nullptr;
     SideGuard side_guard{side, s};
@@ -530,7 +545,17 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         DVAE_TRY(side_for_stream(s, &side));
         DVAE_TRY(fork_side(side, s));
     }
-    if (persist) {
+    if (tiny) {
+        TinyChainArgs a = {};
+        for (int k = 0; k < dirs; ++k)
+            tiny_dir_fwd(a.d[k], w.agg[k], w.gates[k], w.ghn[k], w.hs[k], w.gm[k], w.msg[k], pw + L.whh[k], pw + L.wgm[k],
+                         pw + L.gi[k], pw + L.bhn[k], pw + L.gv[k], k == 0 ? bv.pred_off : bv.succ_off,
+                         k == 0 ? bv.pred_idx : bv.succ_idx, k, 0);
+        a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = dirs;
+        a.sync = reinterpret_cast<unsigned*>(w.sync);
+        a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+        DVAE_TRY(tiny_chain_fwd(a, s));
+    } else if (persist) {
         EncChainArgs a = {};
         for (int k = 0; k < dirs; ++k) {
             EncChainDir& e = a.d[k];
@@ -591,7 +616,8 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     DVAE_TRY(lin_fwd(hgu, ld_hgu, nullptr, pw + L.fc12, Hp, pw + L.b12, w.out12, 2 * d.NZp, B, 2 * d.NZp, Hp, 0, 0, s));
     // (a persistent chain whose bounded wait ran out leaves its flag set: mu and logvar become NaN, never stale numbers)
     EW(split_mu_logvar_kernel, (long)B * d.nz, w.out12, mu, logvar, B, d.nz, d.NZp,
-       persist ? reinterpret_cast<const unsigned*>(w.sync) + ENC_CHAIN_SYNC_WORDS - 64 : nullptr);
+       tiny ? reinterpret_cast<const unsigned*>(w.sync) + TINY_CHAIN_SYNC_WORDS - 64
+            : persist ? reinterpret_cast<const unsigned*>(w.sync) + ENC_CHAIN_SYNC_WORDS - 64 : nullptr);
     return DVAE_OK;
 }
 
@@ -618,10 +644,11 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // stream picks it up with the join below, long after it has finished
     Side* side = nullptr;
     SideGuard side_guard{side, s};
-    const bool merged = fused && dirs == 2 && !d.bn && chain_merge_dirs();
+    const bool tiny = fused && chain_tiny_persist(d, c->B, dirs);  // both directions' reverse chains as one persistent launch
+    const bool merged = !tiny && fused && dirs == 2 && !d.bn && chain_merge_dirs();
     // per-level weight-gradient terms beside the chains: on the (idle) side stream with one direction, on a third
     // stream with two (both other streams walk a chain)
-    const bool wbl = !d.bn && !merged && wgrad_by_level(2);
+    const bool wbl = !d.bn && !merged && !tiny && wgrad_by_level(2);
     if (dirs == 2 || wbl) DVAE_TRY(side_for_stream(s, &side));
     hipStream_t wg_stream = wbl ? (dirs == 2 ? side->aux : side->stream) : nullptr;
     if (dirs == 2) {
@@ -738,12 +765,29 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // as in the forward pass: two streams, enqueued level by level in turn
     // (as in the forward pass: optionally both directions of a level as one grid)
     if (dirs == 2) DVAE_TRY(join_side(side, s));  // the type sort (csr_on_side)
-    if (dirs == 2 && !merged) {
+    if (dirs == 2 && !merged && !tiny) {
         DVAE_TRY(fork_side(side, s));
         DVAE_TRY(begin_dir(1, side->stream));
     }
     DVAE_TRY(begin_dir(0, s));
-    if (d.bn) {
+    if (tiny) {
+        if (dirs == 2) DVAE_TRY(begin_dir(1, s));
+        TinyChainArgs a = {};
+        for (int k = 0; k < dirs; ++k) {
+            TinyChainDir& e = a.d[k];
+            tiny_dir_fwd(e, w.agg[k], w.gates[k], w.ghn[k], w.hs[k], w.gm[k], w.msg[k], pw + L.whh[k], pw + L.wgm[k],
+                         pw + L.gi[k], pw + L.bhn[k], pw + L.gv[k], nullptr, nullptr, k, 0);
+            e.dhs = w.dhs[k]; e.dgm = w.dgm[k]; e.dgh = w.dgh[k]; e.dgin = w.dgin[k]; e.dagg = w.dagg[k];
+            e.toff = k == 0 ? bv.succ_off : bv.pred_off;
+            e.tidx = k == 0 ? bv.succ_idx : bv.pred_idx;
+        }
+        a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = dirs;
+        a.sync = reinterpret_cast<unsigned*>(w.sync);
+        a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+        a.poison = pg + L.whh[0];  // a timed-out wait turns the gradients NaN (the weight-gradient products below add to it)
+        DVAE_TRY(tiny_chain_bwd(a, s));
+        if (dirs == 2) DVAE_TRY(fork_side(side, s));  // the two directions' weight gradients on two streams
+    } else if (d.bn) {
         if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
         DVAE_TRY(run_dir_bn(0, s));
     } else if (merged) {
@@ -839,7 +883,17 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
     const bool fused = chain_fused(d, c->B);
-    if (fused) {
+    const bool tiny = fused && !by_level && chain_tiny_persist(d, c->B);  // the decoder's chain as one persistent launch
+    if (tiny) {
+        TinyChainArgs a = {};
+        tiny_dir_fwd(a.d[0], w.agg, w.gates, w.ghn, w.st, w.gm, w.msg, whh, pw + L.wgm[0], gi, bhn, pw + L.gv[0],
+                     bv.pred_off, bv.pred_idx, 0, 1);
+        a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = 1;
+        a.sync = reinterpret_cast<unsigned*>(w.sync);
+        a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+        a.poison = w.sums;  // a timed-out wait turns the loss NaN (the pair kernel adds its sum to it)
+        DVAE_TRY(tiny_chain_fwd(a, s));
+    } else if (fused) {
         DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
     } else {
         DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
@@ -857,7 +911,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
         DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + (long)nB * 3 * Hp, gi, bv.p_type, bhn, w.agg + (long)nB * Hp, Hp,
                                         w.st + (long)nB * Hp, Hp, w.ghn + (long)nB * Hp, PT, Hp, s));
     } else {
-        for (int v = 0; v < n; ++v) {
+        for (int v = 0; v < n && !tiny; ++v) {
             const long r0 = (long)v * B;
             if (v > 0 && fused) {
                 DVAE_TRY(dvae_gru_level_fwd(w.agg + r0 * Hp, Hp, whh, gi, bv.types + r0, bhn, w.gates + r0 * 3 * Hp,
@@ -1018,13 +1072,28 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
         // (only the last vertex's rows of d gm are not written by the chain below)
         DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
-        const bool wbl = wgrad_by_level() && wbl_size_ok(d, B);
+        const bool tiny = fused && chain_tiny_persist(d, B);  // the reverse chain as one persistent launch
+        const bool wbl = !tiny && wgrad_by_level() && wbl_size_ok(d, B);
         hipStream_t s2 = side->stream;
+        if (tiny) {
+            TinyChainArgs a = {};
+            TinyChainDir& e = a.d[0];
+            tiny_dir_fwd(e, w.agg, w.gates, w.ghn, w.st, w.gm, w.msg, whh, pw + L.wgm[0], pw + L.gi[2], pw + L.bhn[2],
+                         pw + L.gv[0], nullptr, nullptr, 0, 1);
+            e.dhs = w.dst; e.dgm = w.dgm; e.dgh = w.dgh; e.dgin = w.dgin; e.dagg = w.dagg;
+            e.toff = bv.succ_off; e.tidx = bv.succ_idx;
+            e.gsrc2 = w.dagg + p0 * Hp; e.off2 = bv.pt_off; e.idx2 = bv.pt_idx;
+            a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = 1;
+            a.sync = reinterpret_cast<unsigned*>(w.sync);
+            a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+            a.poison = pg + L.whh[2];  // a timed-out wait turns the gradients NaN (the weight-gradient products add to it)
+            DVAE_TRY(tiny_chain_bwd(a, s));
+        }
         if (wbl) {  // the partial rows' d gh is final: their term of dWhh starts the side stream's run beside the chain
             DVAE_TRY(fork_side(side, s));
             DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2));
         }
-        for (int v = n - 1; v >= 0; --v) {
+        for (int v = n - 1; v >= 0 && !tiny; --v) {
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
             if (v < n - 1 && !fused) {
@@ -1068,7 +1137,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     }
     // the GRU's remaining weight gradients go to the side stream, behind the predictors' and the per-level terms
     DVAE_TRY(fork_side(side, s));
-    const bool wbl_done = !d.bn && wgrad_by_level() && wbl_size_ok(d, B);
+    const bool wbl_done = !d.bn && wgrad_by_level() && wbl_size_ok(d, B) && !(fused && chain_tiny_persist(d, B));
     if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream));
     else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
     // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------

@@ -52,6 +52,12 @@ class GradSumReducer(object):
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
         self._early = None
+        # overlap = True: the decoder-only part is all-reduced asynchronously from inside backward(), beside the
+        # encoder's backward; False: one all-reduce of the whole buffer after backward() (bench.py --allreduce after)
+        self.overlap = True
+        # timing hook (bench.py): when set to a list, decoder_grads_ready() appends a timing event recorded on the
+        # compute stream at the point where the decoder's gradients are final (= where the early part is launched)
+        self.mark_decoder_done = None
         self.extra_params = []
         # True while the flat buffer is known to hold zeros (FlatAdam's kernel leaves it zeroed after a step and the
         # model clears the flag before it adds gradients): zero() is then free.  Code that writes into the .grad views
@@ -101,7 +107,11 @@ class GradSumReducer(object):
         """Called by the model when loss.backward() has added the decoder's gradients: starts the
         SUM all-reduce of the decoder-only part asynchronously (RCCL orders it after the work
         already enqueued on the compute stream) so that it overlaps the encoder's backward."""
-        if self.n_early == 0 or self._early is not None or not self._collective():
+        if self.mark_decoder_done is not None and self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            self.mark_decoder_done.append(ev)
+        if not self.overlap or self.n_early == 0 or self._early is not None or not self._collective():
             return
         if not self.flat.is_cuda or dist.get_backend() != "nccl":
             return

@@ -81,6 +81,7 @@ class _EncodeFn(torch.autograd.Function):
                    "dvae_encode_forward")
         ctx.model, ctx.batch, ctx.ws, ctx.pw = model, batch, ws, pw
         ctx.n_params = len(params)
+        model._pw_hold(pw, ctx)  # this graph reads pw again in its backward pass
         return mu, logvar
 
     @staticmethod
@@ -98,6 +99,7 @@ class _EncodeFn(torch.autograd.Function):
                                             ctx.pw.data_ptr(), ctx.ws.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(),
                                             pg.data_ptr(), _stream()), "dvae_encode_backward")
         grads = model._unpack(ctx.pw, pg, model._enc_names)
+        model._pw_release(ctx)
         ctx.ws = ctx.pw = None  # release the workspace and the packed weights (which can then be re-packed in place)
         return (None, None) + tuple(grads)
 
@@ -121,6 +123,7 @@ class _LossFn(torch.autograd.Function):
                                          float(beta), out3.data_ptr(), _stream()), "dvae_loss_forward")
         ctx.model, ctx.batch, ctx.ws, ctx.pw = model, batch, ws, pw
         ctx.args = (mu_c, lv_c, eps, float(eps_scale), int(training), float(beta))
+        model._pw_hold(pw, ctx)
         return out3
 
     @staticmethod
@@ -142,6 +145,7 @@ class _LossFn(torch.autograd.Function):
                                           g3.data_ptr(), dmu.data_ptr(), dlogvar.data_ptr(), pg.data_ptr(), _stream()),
                    "dvae_loss_backward")
         grads = model._unpack(ctx.pw, pg, model._dec_names)
+        model._pw_release(ctx)
         ctx.ws = ctx.pw = None
         if model._grad_sink and getattr(model, "_reducer", None) is not None:
             model._reducer.decoder_grads_ready()
@@ -205,6 +209,7 @@ class DVAE(nn.Module):
         self._pw = None
         self._pw_key = None
         self._pw_dirty = False
+        self._pw_holders = None  # weak set of the autograd contexts that still read self._pw in their backward pass
         self._named_cache = None
         self._grad_sink = getattr(self, "_grad_sink", False)
         self._reducer = getattr(self, "_reducer", None)
@@ -232,12 +237,26 @@ class DVAE(nn.Module):
         named = self._named()
         return [named[k] for k in names]
 
+    def _pw_hold(self, pw, ctx):
+        """`ctx` (an autograd context of _EncodeFn / _LossFn) reads the packed buffer `pw` again in its backward
+        pass: until that has run -- or the graph is dropped and the context collected -- the buffer must not be
+        re-packed in place.  Held weakly: a graph that is thrown away without backward() releases by itself."""
+        import weakref
+        if pw is not self._pw:
+            return
+        if self._pw_holders is None:
+            self._pw_holders = weakref.WeakSet()
+        self._pw_holders.add(ctx)
+
+    def _pw_release(self, ctx):
+        if self._pw_holders is not None:
+            self._pw_holders.discard(ctx)
+
     def _packed_weights(self):
         """Zero-padded device copy of the weights, rebuilt when any parameter changed (optimizer steps bump
         tensor versions; FlatAdam, which writes through raw pointers, sets `_pw_dirty`).  The buffer is kept
         and re-packed in place (one launch, padding stays zero) unless a live autograd graph still holds it
-        for its backward pass: then a fresh one is built."""
-        import sys
+        for its backward pass (`_pw_hold`): then a fresh one is built."""
         lib = _lib.load()
         table = self._param_table()
         first = next(p for p in table if p is not None)
@@ -253,16 +272,17 @@ class DVAE(nn.Module):
             if p is not None and (p.dtype != torch.float32 or not p.is_contiguous()):
                 raise _lib.DvaeHipError("parameters must be contiguous float32")
         arr = (C.c_void_p * _lib.NUM_PARAMS)(*[p.data_ptr() if p is not None else None for p in table])
-        # same set of parameters as the buffer was packed from (absent ones leave zeros), and nobody else holds it
-        # (references: the attribute and getrefcount's argument)
+        # same set of parameters as the buffer was packed from (absent ones leave zeros), and no autograd graph that
+        # was built on it still waits for its backward pass
         reuse = (self._pw is not None and self._pw.device == first.device and self._pw_key is not None and
-                 [k is None for k in key] == [k is None for k in self._pw_key] and sys.getrefcount(self._pw) <= 2)
+                 [k is None for k in key] == [k is None for k in self._pw_key] and not self._pw_holders)
         if reuse:
             _lib.check(lib.dvae_repack_weights(C.byref(self._desc), arr, self._pw.data_ptr(), _stream()), "dvae_repack_weights")
         else:
             pw = torch.empty(self._n_packed, dtype=torch.float32, device=first.device)
             _lib.check(lib.dvae_pack_weights(C.byref(self._desc), arr, pw.data_ptr(), _stream()), "dvae_pack_weights")
             self._pw = pw
+            self._pw_holders = None  # contexts of the old buffer keep it alive themselves (ctx.pw)
         self._pw_key, self._pw_dirty = key, False
         return self._pw
 
@@ -331,6 +351,7 @@ class DVAE(nn.Module):
     def _apply(self, fn, *a, **kw):
         self.device = None
         self._pw = None
+        self._pw_holders = None
         self._named_cache = None
         return super(DVAE, self)._apply(fn, *a, **kw)
 

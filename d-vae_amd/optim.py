@@ -65,8 +65,9 @@ class FlatAdam(torch.optim.Optimizer):
                                           self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]),
                                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, zero,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dvae_adam_step_f32")
-        if zero:
-            r.clean = True
+        # (set either way: with the sink detached autograd's own accumulation writes into the .grad views behind the
+        # reducer's back, so the buffer is only known to be zero when THIS step's kernel zeroed it)
+        r.clean = bool(zero)
         # the kernel wrote through raw pointers: tensor versions did not move, so the packed copy is stale
         self.model._pw_dirty = True
         if self.extra is not None:

@@ -364,6 +364,78 @@ def test_grad_sink_and_flat_adam_match_autograd_and_torch_adam():
     assert all(sd[k].shape == sd_ref[k].shape for k in sd)
 
 
+def test_detaching_the_sink_between_steps_does_not_leak_gradients():
+    """FlatAdam's kernel leaves the flat gradient buffer zeroed and marks the reducer clean only while the
+    gradient sink is attached.  With the sink detached after a step, autograd accumulates into the .grad views behind
+    the reducer's back: the next zero_grad() must really zero them, or gradients pile up from step to step."""
+    rng = np.random.default_rng(5)
+    n, T, hs, nz, B = 8, 8, 24, 6, 12
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=0)
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.3, True)
+    ga = dvae_amd.GraphArrays.from_dense(types, adj, n_g)
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    model = make_model("DVAE", ctor, 3).cuda()
+    opt = dvae_amd.optim.FlatAdam(model, lr=0.0)  # lr 0: the weights stay put, every step has the same gradient
+
+    def grads():
+        opt.zero_grad()
+        mu, lv = model.encode(ga)
+        l, _, _ = model.loss(mu, lv, ga, eps=eps)
+        l.backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    g0 = grads()
+    opt.step()                       # sink attached: the kernel zeroes the buffer, reducer.clean = True
+    model.attach_grad_sink(False)    # from here on autograd's AccumulateGrad writes the .grad views
+    g1 = grads()
+    opt.step()                       # must NOT leave `clean` set: nothing zeroed the buffer
+    assert not opt.reducer.clean
+    g2 = grads()
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k
+        assert rel_err(g2[k], g0[k]) < 1e-5, k  # (2x if the stale flag had skipped the zeroing)
+
+
+def test_packed_weights_are_not_repacked_under_a_live_graph():
+    """The packed weight buffer is re-packed IN PLACE after an optimizer step -- unless an autograd graph built on it
+    still waits for its backward pass (models.py: _pw_hold): its backward must see the weights of its forward."""
+    rng = np.random.default_rng(6)
+    n, T, hs, nz, B = 8, 8, 24, 6, 8
+    ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=1)
+    types, adj, n_g = _random_batch(rng, B, n, T, 0.3, False)
+    ga = dvae_amd.GraphArrays.from_dense(types, adj, n_g)
+    eps = torch.from_numpy(rng.standard_normal((B, nz)).astype(np.float32))
+    model = make_model("DVAE", ctor, 4).cuda()
+    mu, lv = model.encode(ga)
+    l, _, _ = model.loss(mu, lv, ga, eps=eps)
+    pw0 = model._pw
+    ptr0 = pw0.data_ptr()
+    assert len(model._pw_holders) == 2
+    with torch.no_grad():            # "an optimizer step" while the graph is alive
+        for p in model.parameters():
+            p.mul_(0.5)
+    mu2, _ = model.encode(ga)        # needs new packed weights: must not touch the held buffer
+    assert model._pw.data_ptr() != ptr0
+    l.backward()                     # the old graph's backward still reads pw0
+    ref = make_model("DVAE", ctor, 4).cuda()
+    m, v = ref.encode(ga)
+    lr, _, _ = ref.loss(m, v, ga, eps=eps)
+    lr.backward()
+    rg = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        if rg[k].grad is not None:
+            assert rel_err(p.grad, rg[k].grad) < 1e-5, k
+    # with no graph alive the buffer is reused in place
+    del mu2
+    ptr1 = model._pw.data_ptr()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(2.0)
+    with torch.no_grad():
+        model.encode(ga)
+    assert model._pw.data_ptr() == ptr1
+
+
 # ---------------------------------------------------------------- generation (models.py:747-804)
 DECODE = golden_files("decode_*")
 
