@@ -11,8 +11,11 @@ one rank per GPU, per-GPU batch fixed (weak scaling), no collective other than
 the one gradient all-reduce.  Rank 0 prints ONE JSON line.
 
 The JSON line carries
-  roofline      the dominant kernel (fp32 MFMA GEMM) timed live with HIP events on
-                the stream it runs on, on the largest product of the step
+  roofline      the dominant kernel family of the step timed live with HIP events on the stream
+                it runs on: the fused GRU level kernel of the state chains (chain_kernel, the
+                largest share of the step's kernel time at cfg 2 / cfg 4) where the step runs
+                it, otherwise the MFMA GEMM on the step's largest product
+  roofline_gemm the fp32 / bf16 MFMA GEMM on the largest product of the step (always)
   step_roofline whole-step algorithmic FLOPs (6 * F_alg) / step time
   cpu_baseline  the oracle's reference-style CPU port timed on the host cores
                 (rank 0, N = 1 only, bounded sample)
@@ -49,6 +52,9 @@ def parse_args(argv=None):
                     help="weak: the config's per-GPU batch on every rank; strong: a fixed global batch "
                          "(--global-batch, default 8 x the per-GPU batch: cfg 4 = 8192) ceil-split over the ranks")
     ap.add_argument("--global-batch", type=int, default=0)
+    ap.add_argument("--allreduce", default="overlap", choices=["overlap", "after"],
+                    help="N > 1: overlap = the decoder-only part of the gradient buffer is all-reduced from inside "
+                         "backward(), beside the encoder's backward (default); after = one all-reduce after backward()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -137,6 +143,18 @@ def measured_traffic(shape):
     if list(pm.get("shape_MNK", [9251, 2048, 512])) != list(shape) or "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:
         return None, os.path.relpath(path, ROOT)
     return (2.0 * pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(path, ROOT)
+
+def measured_chain_traffic(shape):
+    """Memory-side bytes of ONE launch of the GRU level kernel from the committed PMC passes
+    (tools/pmc_chain.sh -> profiles/rNN_chain_pmc.json), as measured_traffic(); None when absent or another shape."""
+    path = newest_profile("chain_pmc.json")
+    if path is None:
+        return None, None
+    pm = json.load(open(path))
+    if list(pm.get("shape_MNK", [])) != list(shape) or "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:
+        return None, os.path.relpath(path, ROOT)
+    return (2.0 * pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(path, ROOT)
+
 
 CONFIGS = {
     # name: (class, ctor kwargs, per-GPU batch, generator)
@@ -264,6 +282,54 @@ def time_dominant_gemm(cfg, batch, iters=30, bf16=False):
                 avg_ms=ms, achieved=flops / (ms * 1e-3) / 1e12)
 
 
+def chain_level_is_fused(cfg, B, bf16):
+    """does the step run its chain levels on chain_kernel (csrc/train.hip: chain_level_small)?  fp32 mode, DVAE,
+    levels of half a round to two rounds of the chip in 64 x 32 tiles"""
+    if bf16 or cfg["cls"] == "DVAE_BN":
+        return False
+    Hp = (cfg["hs"] + 31) // 32 * 32
+    tiles = ((B + 63) // 64) * (Hp // 32)
+    return 128 <= tiles <= 512
+
+
+def time_chain_level(cfg, B, iters=200):
+    """HIP-event timing of the dominant kernel family of the fp32 step at cfg 2 / cfg 4: one GRU LEVEL of a state
+    chain (csrc/chain.hip chain_kernel<3, false, 0, ...>: hidden product h_prev W_hh^T [B x Hp] x [Hp x 3Hp] and the
+    GRUCell tail in one launch), on B rows, through the C-ABI entry point the step itself calls
+    (dvae_gru_level_fwd).  Algorithmic FLOPs per launch = 2 * B * Hp * 3Hp (the product; the tail is not counted)."""
+    lib = dvae_amd._lib.load()
+    Hp = (cfg["hs"] + 31) // 32 * 32
+    T = cfg["nvt"]
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    hprev = torch.randn(B, Hp, device=dev, generator=g)
+    whh = torch.randn(3 * Hp, Hp, device=dev, generator=g) / Hp ** 0.5
+    gi = torch.randn(32, 3 * Hp, device=dev, generator=g)
+    bhn = torch.randn(Hp, device=dev, generator=g)
+    types = torch.randint(0, T, (B,), device=dev, generator=g, dtype=torch.int32)
+    gates = torch.empty(B, 3 * Hp, device=dev)
+    ghn = torch.empty(B, Hp, device=dev)
+    hout = torch.empty(B, Hp, device=dev)
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def launch():
+        return lib.dvae_gru_level_fwd(hprev.data_ptr(), Hp, whh.data_ptr(), gi.data_ptr(), types.data_ptr(),
+                                      bhn.data_ptr(), gates.data_ptr(), ghn.data_ptr(), hout.data_ptr(), Hp, B, Hp, sp)
+    for _ in range(10):
+        dvae_amd._lib.check(launch())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        launch()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * Hp * 3 * Hp
+    return dict(kernel="chain_kernel<3, false, 0, 4, ...> GRU level: h_prev W_hh^T + GRUCell tail (v_mfma_f32_32x32x2_f32)",
+                shape=[B, 3 * Hp, Hp], avg_ms=ms, achieved=flops / (ms * 1e-3) / 1e12)
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """Oracle 'refstyle' port (per-vertex / per-graph loops mirroring the reference
     op for op) + Adam, on the host cores.  Bounded sample: B = 32 graphs of the same
@@ -334,6 +400,7 @@ def main():
     # flat gradient buffer (its slices are the parameters' .grad; backward adds into them in place) and
     # Adam as one launch over the flat parameter buffer: the update rule of train.py:174
     reducer = dvae_amd.dist.GradSumReducer(model)
+    reducer.overlap = args.allreduce == "overlap"
     opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
 
     # pre-packed batches.  weak: every rank owns B graphs per step (its own synthetic draw);
@@ -366,21 +433,25 @@ def main():
 
     stream = torch.cuda.current_stream()
     exchange = world > 1 or os.environ.get("DVAE_FORCE_COLLECTIVE") == "1"
-    ar_events = []
+    ar_events = []   # per timed step: (decoder gradients final, backward done, all-reduce done) on the compute stream
 
-    def step(i, timed=False):
+    def step(i, timed=False, events=None):
         b = batches[i % n_batches]
         reducer.zero()
         mu, logvar = model.encode(b)
         loss, _, _ = model.loss(mu, logvar, b, eps=eps[i % n_batches])
-        loss.backward()
-        if exchange and timed:
+        sink = events if events is not None else (ar_events if (exchange and timed) else None)
+        if sink is not None:
+            reducer.mark_decoder_done = marks = []
+            loss.backward()
+            reducer.mark_decoder_done = None
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             reducer.all_reduce()
             e1.record(stream)
-            ar_events.append((e0, e1))
+            sink.append((marks[0] if marks else None, e0, e1))
         else:
+            loss.backward()
             reducer.all_reduce()
         opt.step()
         return loss
@@ -405,17 +476,61 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    # the exchange step as the compute stream sees it (the part not hidden behind the encoder's backward)
-    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events) if ar_events else 0.0
+    # the exchange step as the compute stream sees it (the part not hidden behind the encoder's backward), and the
+    # span from the point where the decoder's gradients are final -- where the early part is launched in overlap
+    # mode -- to the end of the last all-reduce
+    ar_ms = sum(a.elapsed_time(b) for _, a, b in ar_events) / len(ar_events) if ar_events else 0.0
+    ar_span = [m.elapsed_time(b) for m, _, b in ar_events if m is not None]
+    ar_span_ms = sum(ar_span) / len(ar_span) if ar_span else 0.0
     loss_global = float(reducer.reduce_scalars(last)[0].item())  # sum over the ranks' shards of the last global batch
+
+    # host cost of ONE step with an empty queue in front of it: enqueue one step right after a device sync, read the
+    # host clock before any further sync (median of 9).  Unlike host_enqueue_ms_per_step (K steps back to back, which
+    # includes the time the host spends blocked on a full queue) this is the host's own time per step.
+    unblocked = []
+    for i in range(9):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i)
+        unblocked.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    unblocked.sort()
+    host_unblocked_ms = unblocked[len(unblocked) // 2]
+
+    # encoder backward (decoder gradients final -> backward() done) with and without the early all-reduce in flight
+    enc_bwd = {}
+    if exchange:
+        for mode in ("overlap", "after"):
+            reducer.overlap = mode == "overlap"
+            evs = []
+            for i in range(6):
+                step(i, events=evs)
+            torch.cuda.synchronize()
+            v = [m.elapsed_time(a) for m, a, _ in evs[1:] if m is not None]
+            enc_bwd[mode] = sum(v) / len(v) if v else None
+        reducer.overlap = args.allreduce == "overlap"
+    barrier()
 
     if rank == 0:
         macs, E, od0 = f_alg_macs(cfg, batches[0].arrays)
         train_flop_per_dag = 6.0 * macs
         dags_per_s = Bg * args.steps / dt
         exec_flop_per_step = 6.0 * executed_mfma_macs(cfg, batches[0].counts)
-        roof = time_dominant_gemm(cfg, batches[0], bf16=bf16)
-        traffic, traffic_src = (None, None) if bf16 else measured_traffic(roof["shape"])
+        roof_gemm = time_dominant_gemm(cfg, batches[0], bf16=bf16)
+        traffic, traffic_src = (None, None) if bf16 else measured_traffic(roof_gemm["shape"])
+        gemm_line = {"bound": "mfma", "achieved": roof_gemm["achieved"], "peak": peak, "unit": "TFLOP/s",
+                     "frac": roof_gemm["achieved"] / peak, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": roof_gemm["kernel"], "shape_MNK": roof_gemm["shape"], "avg_launch_ms": roof_gemm["avg_ms"]}
+        if chain_level_is_fused(cfg, B_rank, bf16):
+            # the dominant family of this step (largest share of kernel time in profiles/rNN_roofline_by_kernel.json)
+            roof = time_chain_level(cfg, B_rank)
+            ctraffic, ctraffic_src = measured_chain_traffic(roof["shape"])
+            roof_line = {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": roof["achieved"] / peak, "traffic": ctraffic, "traffic_source": ctraffic_src,
+                         "kernel": roof["kernel"], "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"],
+                         "flop_per_launch": 2.0 * roof["shape"][0] * roof["shape"][1] * roof["shape"][2]}
+        else:
+            roof_line = gemm_line
         out = {
             "metric": "DAGs/sec train step (ENAS6, hs=501)" if args.config in ("cfg1", "cfg2") else
                       "DAGs/sec train step (%s)" % args.config,
@@ -435,13 +550,17 @@ def main():
                        "train_gflop_per_dag": train_flop_per_dag / 1e9, "grad_allreduce_mb": reducer.nbytes() / 1e6,
                        "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0,
                        "collective_backend": backend if world > 1 else "none",
-                       "allreduce_ms_per_step": ar_ms,
+                       "allreduce": args.allreduce if exchange else "none",
+                       "allreduce_ms_per_step": ar_ms,          # on the compute stream, after backward(): the exposed part
+                       "allreduce_total_ms": ar_span_ms,        # decoder gradients final -> last all-reduce done
+                       "allreduce_early_mb": (reducer.n_early * 4 / 1e6) if (exchange and reducer.overlap) else 0.0,
+                       "encode_bwd_ms": enc_bwd,                # {"overlap": with the early part in flight, "after": without}
                        "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                       "host_enqueue_ms_per_step_unblocked": host_unblocked_ms,
                        "launches_per_step": launches,  # the library's kernel launches (its memsets / copies and torch's own are not counted)
                        "loss_last_step": loss_global},
-            "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": roof["achieved"] / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": roof["kernel"], "shape_MNK": roof["shape"], "avg_launch_ms": roof["avg_ms"]},
+            "roofline": roof_line,
+            "roofline_gemm": gemm_line,
             # algorithmic rate (the SURVEY 8d contract figure: every DISTINCT module evaluation at dense cost, 6 F_alg
             # per DAG) and, beside it, the FLOPs the matrix units really execute per step (padded, de-duplicated):
             # `executed` is the step's MFMA occupancy, `achieved` credits work the restatement avoids

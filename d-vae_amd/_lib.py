@@ -23,6 +23,11 @@ class BatchCounts(C.Structure):
                  "R", "RL", "NCE", "HGF", "HGB", "level_major")] + [("total_ints", C.c_int64)]
 
 
+class BatchCaps(C.Structure):
+    """dvae_batch_caps (include/dvae_hip.h): the edge-dependent counts a shape-stable export is padded to"""
+    _fields_ = [(k, C.c_int32) for k in ("E", "PT", "PL", "NB", "CH")]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("a_rows", C.c_void_p), ("b_rows", C.c_void_p), ("c_rows", C.c_void_p),
@@ -85,9 +90,11 @@ SIGNATURES = {
     "dvae_pack_weights": (_I, [_MD, C.POINTER(_P), _P, _P]),
     "dvae_unpack_grads": (_I, [_MD, _P, _P, C.POINTER(_P), C.POINTER(C.c_uint8), _I, _P]),
     "dvae_adam_step_f32": (_I, [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _I, _I, _P]),
+    "dvae_adam_step_dev_f32": (_I, [_P, _P, _P, _P, C.c_int64, _P, _F, _F, _F, _P, _I, _P]),
     "dvae_repack_weights": (_I, [_MD, C.POINTER(_P), _P, _P]),
     "dvae_batch_create": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, C.POINTER(_P), _BC]),
     "dvae_batch_export": (_I, [_P, _P, C.c_int64]),
+    "dvae_batch_export_padded": (_I, [_P, C.POINTER(BatchCaps), _P, C.c_int64, _BC]),
     "dvae_batch_destroy": (None, [_P]),
     "dvae_decode_ws_floats": (C.c_int64, [_MD, _I]),
     "dvae_decode": (_I, [_MD, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

@@ -36,6 +36,17 @@ namespace dvae {
 __device__ __forceinline__ void tiny_fail(const TinyChainArgs& a) {
     if (threadIdx.x == 0 && a.poison) atomicAdd(a.poison, __builtin_nanf(""));
 }
+// Signal of a phase whose hand-off stores were all issued by wave 0 (the tail wave): that wave drains its write-through
+// stores and its lane 0 adds to the counter -- no workgroup barrier (it signals for no other wave); the next phase's
+// chain_wait is the barrier that keeps the other waves off the LDS exchange buffer until wave 0 has read it.
+// Call with the hand-off stores issued and the phase's plain stores (read only by later kernels, or by this lane after
+// the next drain) NOT yet issued: they then travel under the next phase's wait.
+__device__ __forceinline__ void tail_signal(unsigned* cnt, int kq, int lane) {
+    if (kq == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ float4 ld4_l2(const float* base, long elem) {  // L1-bypassing load of data written in this launch
@@ -173,15 +184,17 @@ __global__ __launch_bounds__(512) void tiny_chain_fwd_kernel(TinyChainArgs a) {
     }
                 GRU1(x) GRU1(y) GRU1(z) GRU1(w)
 #undef GRU1
+                st4_sc1(rsrc_of(e.hs + r0 * Hp), (unsigned)((orow * Hp + ocol) * 4), Hn);
+                tail_signal(cnt, kq, lane);
                 float* g = e.gates + (r0 + orow) * 3 * Hp;
                 cst4(g + ocol, R);
                 cst4(g + Hp + ocol, Z);
                 cst4(g + 2 * Hp + ocol, N);
                 cst4(e.ghn + (r0 + orow) * Hp + ocol, GN);
                 if (!product) cst4(e.agg + (r0 + orow) * Hp + ocol, f4zero());  // h_prev = 0: left for the backward pass
-                st4_sc1(rsrc_of(e.hs + r0 * Hp), (unsigned)((orow * Hp + ocol) * 4), Hn);
+            } else {
+                tail_signal(cnt, kq, lane);
             }
-            chain_signal(cnt);
         }
         if (step == n - 1) break;  // the pass's last vertex sends no message
         // ---- gate / mapper level: msg = sigmoid(..) * (..), and the next level's predecessor sum
@@ -213,17 +226,19 @@ __global__ __launch_bounds__(512) void tiny_chain_fwd_kernel(TinyChainArgs a) {
                 const float4 g = make_float4(1.f / (1.f + expf(-pa.x)), 1.f / (1.f + expf(-pa.y)), 1.f / (1.f + expf(-pa.z)),
                                              1.f / (1.f + expf(-pa.w)));
                 const float4 own = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);
-                float* o = e.gm + (r0 + orow) * 2 * Hp;
-                cst4(o + ocol, g);
-                cst4(o + Hp + ocol, m);
-                cst4(e.msg + (r0 + orow) * Hp + ocol, own);
                 // every source of the next level other than this one is a finished level; this level's own message
                 // (if it is a source) comes from registers
                 float4 agg = others;
                 if (mine) f4add(agg, own);
                 st4_sc1(rsrc_of(e.agg + r1 * Hp), (unsigned)((orow * Hp + ocol) * 4), agg);
+                tail_signal(cnt, kq, lane);
+                float* o = e.gm + (r0 + orow) * 2 * Hp;
+                cst4(o + ocol, g);
+                cst4(o + Hp + ocol, m);
+                cst4(e.msg + (r0 + orow) * Hp + ocol, own);  // (re-read by this lane behind a later phase's drain)
+            } else {
+                tail_signal(cnt, kq, lane);
             }
-            chain_signal(cnt);
         }
     }
 }
@@ -277,7 +292,6 @@ __global__ __launch_bounds__(512) void tiny_chain_bwd_kernel(TinyChainArgs a) {
                     float4 s1[1];
                     slices_sum<1>(xch, s1, lane);
                     f4add(D, s1[0]);
-                    cst4(e.dhs + (r0 + orow) * Hp + ocol, D);
                 }
             }
             if (tail) {
@@ -302,10 +316,13 @@ __global__ __launch_bounds__(512) void tiny_chain_bwd_kernel(TinyChainArgs a) {
                 st4_sc1(rg, o, dR);
                 st4_sc1(rg, o + (unsigned)Hp * 4u, dZ);
                 st4_sc1(rg, o + (unsigned)Hp * 8u, dGN);
+                tail_signal(cnt, kq, lane);
+                cst4(e.dhs + (r0 + orow) * Hp + ocol, D);
                 cst4(e.dgin + (r0 + orow) * Hp + ocol, dPN);
                 if (!phase_b) cst4(e.dagg + (r0 + orow) * Hp + ocol, dHP);
+            } else {
+                tail_signal(cnt, kq, lane);
             }
-            chain_signal(cnt);
         }
         if (!phase_b) break;
         // ---- (B)
@@ -337,7 +354,6 @@ __global__ __launch_bounds__(512) void tiny_chain_bwd_kernel(TinyChainArgs a) {
                 slices_sum<1>(xch, s1, lane);
                 float4 d = dHP;
                 f4add(d, s1[0]);
-                cst4(e.dagg + (r0 + orow) * Hp + ocol, d);
                 if (step > 0) {
                     float4 dm_ = others;
                     if (mine) f4add(dm_, d);
@@ -349,8 +365,11 @@ __global__ __launch_bounds__(512) void tiny_chain_bwd_kernel(TinyChainArgs a) {
                     st4_sc1(ro, o, dg);
                     st4_sc1(ro, o + (unsigned)Hp * 4u, dmap);
                 }
+                tail_signal(cnt, kq, lane);
+                cst4(e.dagg + (r0 + orow) * Hp + ocol, d);  // (re-read by this lane's later gathers, behind a later phase's drain)
+            } else {
+                tail_signal(cnt, kq, lane);
             }
-            chain_signal(cnt);
         }
     }
 }

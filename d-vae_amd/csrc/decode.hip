@@ -225,7 +225,7 @@ static int decode_impl(const dvae_model_desc* m, int32_t B, const float* pw, flo
     tl_bf16 = d.bf16;
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
-    set_mode(d, L, pw);
+    ModeGuard mode_guard(d, L, pw);
     GenWs w = carve_gen(d, B, ws);
     const int n = d.n, Hp = d.Hp, HEp = d.HEp, end_type = m->end_type;
     DecState st;
@@ -317,20 +317,34 @@ extern "C" int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw,
 // ---------------------------------------------------------------------------------------------
 static __device__ __align__(256) float scratch[DVAE_DECODE_STATIC_FLOATS];
 
-static int static_scratch_for_current_device(float** out) {
-    static float* ptrs[64];
-    static std::mutex mu;
+// Per device: the array's address, and who used it last.  Calls that overlap on one GPU share the array and would
+// race; calls on ONE stream are ordered by the stream and are fine.  So each call leaves an event behind its work, and
+// a call that arrives on ANOTHER stream while that event has not completed is refused (an error, not a race).
+// Set-up (first call on a device): hipGetSymbolAddress + one hipEventCreate; after that a call allocates nothing.
+// Under stream capture no event is left or queried (a captured record cannot be queried): there the ordering of
+// captured calls is the graph's, i.e. the capturing caller's.
+struct StaticScratch {
+    float* ptr = nullptr;
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+};
+static StaticScratch g_static[64];
+static std::mutex g_static_mu;
+
+static int static_scratch_for_current_device(StaticScratch** out) {
     int dev = 0;
     DVAE_HIP(hipGetDevice(&dev));
     DVAE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ptrs[dev]) {
+    StaticScratch& st = g_static[dev];
+    if (!st.ptr) {
         float* p = nullptr;
         DVAE_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
         DVAE_REQUIRE(p != nullptr && ((uintptr_t)p % 256) == 0, "static scratch: bad symbol address");
-        ptrs[dev] = p;
+        DVAE_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        st.ptr = p;
     }
-    *out = ptrs[dev];
+    *out = &st;
     return DVAE_OK;
 }
 
@@ -345,10 +359,30 @@ extern "C" int dvae_decode_static(const dvae_model_desc* m, int32_t B, const flo
                  "dvae_decode_static: %d graphs of this model need a workspace of %lld floats, the static scratch holds "
                  "%lld; decode fewer graphs per call or use dvae_decode with a caller-provided workspace",
                  B, (long long)need, (long long)DVAE_DECODE_STATIC_FLOATS);
-    float* ws = nullptr;
-    DVAE_TRY(static_scratch_for_current_device(&ws));
+    std::lock_guard<std::mutex> lock(g_static_mu);  // check, enqueue and record as one step against other host threads
+    StaticScratch* st = nullptr;
+    DVAE_TRY(static_scratch_for_current_device(&st));
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (st->pending && !capturing && st->last_stream != s) {
+        const hipError_t q = hipEventQuery(st->done);
+        if (q == hipErrorNotReady)
+            return set_err(DVAE_ERR_ARG, "dvae_decode_static: an earlier call on another stream of this GPU is still running; "
+                                         "overlapping calls share the static scratch and would race -- order them on one "
+                                         "stream, wait for the earlier call, or use dvae_decode with workspaces of your own");
+        if (q != hipSuccess) (void)hipGetLastError();
+        st->pending = false;
+    }
     // (nothing in the workspace has to start at zero: decode_impl writes every word it later reads --
     // running sums and gate buffers are cleared per vertex on the stream -- so the previous call's
     // contents are harmless)
-    return decode_impl(m, B, pw, ws, z, stochastic, u_type, u_edge, types, pred_mask, n_vertices, stream);
+    const int rc = decode_impl(m, B, pw, st->ptr, z, stochastic, u_type, u_edge, types, pred_mask, n_vertices, stream);
+    if (!capturing) {  // also after a failed call: whatever it enqueued before failing still uses the array
+        DVAE_HIP(hipEventRecord(st->done, s));
+        st->pending = true;
+        st->last_stream = s;
+    }
+    return rc;
 }

@@ -20,6 +20,19 @@ static inline void set_mode(const Dims& d, const PackedLayout& L, const float* p
     if (d.bf16) tl_layout = L;
     chain_bf16_context(d.bf16 ? pw : nullptr, &L);  // the fused level kernels find their bf16 weight copies through it
 }
+// Scope of an entry point's mode: set at entry, CLEARED on every exit, so that the thread-local pointer to the packed
+// weights never outlives the call (a later direct dvae_chain_level_batch / dvae_gru_level_fwd call from this thread
+// must not be switched to bf16 inputs because its fp32 weight happens to lie where an old packed buffer was).
+struct ModeGuard {
+    ModeGuard(const Dims& d, const PackedLayout& L, const float* pw) { set_mode(d, L, pw); }
+    ~ModeGuard() {
+        tl_bf16 = 0;
+        tl_pw = nullptr;
+        chain_bf16_context(nullptr, nullptr);
+    }
+    ModeGuard(const ModeGuard&) = delete;
+    ModeGuard& operator=(const ModeGuard&) = delete;
+};
 // A product whose B operand is a packed weight matrix reads the bf16 copy instead (half the bytes, no conversion in the
 // K loop), and a data gradient (B K-major = the weight as stored) reads the TRANSPOSED bf16 copy, which makes it a
 // product of two K-contiguous operands: both then run on gemm_bf16_nn.hip.  Anything the copies cannot serve

@@ -293,8 +293,8 @@ static int pack_impl(const dvae_model_desc* m, const float* const* params, float
             const PackedLayout::Mat& mt = L.mats[i];
             const dim3 grid(cdiv(mt.cols, 32), cdiv(mt.rows, 32)), block(32, 8);
             hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, s, packed + mt.off, halfT + mt.toff, mt.rows, mt.cols);
+            DVAE_LAUNCH_CHECK();  // per launch: every launch is counted and checked (dvae_debug_launch_count)
         }
-        DVAE_LAUNCH_CHECK();
     }
     return DVAE_OK;
 }

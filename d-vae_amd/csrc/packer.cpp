@@ -343,4 +343,67 @@ extern "C" int dvae_batch_export(void* handle, int32_t* out, int64_t out_ints) {
     return DVAE_OK;
 }
 
+// Shape-stable export (include/dvae_hip.h: dvae_batch_export_padded).  The counts that depend on the batch's EDGES --
+// E, PT, PL, NB, CH -- are raised to the caller's caps, so that every batch of the same (B, max_n, nvt, kind, caps) has
+// the SAME counts and therefore the same blob layout, workspace carve-up, launch grids and kernel arguments: a train
+// step on such batches is one fixed launch sequence (capturable once, replayable for ever).  The padding is inert:
+//   pred / succ / partial-list index arrays   longer, the tail is never addressed (the offset arrays bound every read);
+//   partial rows PT .. PT_cap-1               empty predecessor lists, type 0: computed, referenced by no pair, and their
+//                                             gradient rows stay exactly zero;
+//   EB table rows NB .. NB_cap-1              gathered from the first type row: computed, referenced by no pair; the
+//                                             all-zero row moves from NB to NB_cap (pair_h entries are renumbered);
+//   backward chunks CH .. CH_cap-1            EMPTY chunks, one per padding row of the EB table (its gradient row is
+//                                             written whole, with zeros) and the rest on the all-zero row.
+// Only batches whose graphs all have max_n vertices qualify (everything else in the counts is then a function of
+// (B, max_n)); anything above a cap is an error the caller answers with the plain export.
+extern "C" int dvae_batch_export_padded(void* handle, const dvae_batch_caps* caps, int32_t* out, int64_t out_ints,
+                                        dvae_batch_counts* counts_out) {
+    DVAE_REQUIRE(handle && caps && out && counts_out, "dvae_batch_export_padded: null pointer");
+    PackedBatch* pb = (PackedBatch*)handle;
+    const dvae_batch_counts& c = pb->c;
+    DVAE_REQUIRE(c.R == (c.n - 1) * c.B && c.NA == (c.n - 1) * c.B && c.HGF == (c.is_bn ? (c.n - 2) * c.B : c.B),
+                 "dvae_batch_export_padded: every graph of the batch must have max_n vertices");
+    DVAE_REQUIRE(c.E <= caps->E && c.PT <= caps->PT && c.PL <= caps->PL && c.NB <= caps->NB,
+                 "dvae_batch_export_padded: the batch exceeds the caps (E %d/%d, PT %d/%d, PL %d/%d, NB %d/%d)", c.E, caps->E,
+                 c.PT, caps->PT, c.PL, caps->PL, c.NB, caps->NB);
+    const int pad_rows = caps->NB - c.NB;
+    DVAE_REQUIRE(c.CH + pad_rows <= caps->CH, "dvae_batch_export_padded: the batch exceeds the caps (CH %d + %d padding rows / %d)",
+                 c.CH, pad_rows, caps->CH);
+    dvae_batch_counts q = c;
+    q.E = caps->E; q.PT = caps->PT; q.PL = caps->PL; q.NB = caps->NB; q.CH = caps->CH;
+    q.total_ints = walk_batch(q, [](int, int64_t, int64_t) {});
+    DVAE_REQUIRE(out_ints >= q.total_ints, "dvae_batch_export_padded: buffer too small (%lld < %lld)", (long long)out_ints,
+                 (long long)q.total_ints);
+    memset(out, 0, sizeof(int32_t) * (size_t)q.total_ints);
+    walk_batch(q, [&](int id, int64_t off, int64_t) {
+        int32_t* dst = out + off;
+        if (id == 19) { memcpy(dst, pb->pair_t.data(), pb->pair_t.size()); return; }
+        const std::vector<int32_t>& a = pb->arr[id];
+        if (!a.empty()) memcpy(dst, a.data(), sizeof(int32_t) * a.size());
+        switch (id) {
+        case 9:  // p_off [PT_cap + 1]: the padding rows' lists are empty
+            for (int r = c.PT + 1; r <= q.PT; ++r) dst[r] = c.PL;
+            break;
+        case 15:  // rowsB [NB_cap]: the padding rows read the first type row of the state table
+            for (int r = c.NB; r < q.NB; ++r) dst[r] = c.nB;
+            break;
+        case 17:  // pair_h: the all-zero row is row NB_cap now
+            for (int k = 0; k < c.NP; ++k)
+                if (dst[k] == c.NB) dst[k] = q.NB;
+            break;
+        case 23:  // ch_off [CH_cap + 1]: empty chunks behind the real ones
+            for (int k = c.CH + 1; k <= q.CH; ++k) dst[k] = c.NP;
+            break;
+        case 24:  // ch_row [CH_cap]: one empty chunk per padding row (written whole: zeros), the rest on the all-zero row
+            for (int k = 0; k < c.CH; ++k)
+                if ((dst[k] & 0x7fffffff) == c.NB) dst[k] = (int32_t)((uint32_t)q.NB | ((uint32_t)dst[k] & 0x80000000u));
+            for (int k = c.CH; k < q.CH; ++k) dst[k] = k - c.CH < pad_rows ? c.NB + (k - c.CH) : q.NB;
+            break;
+        default: break;
+        }
+    });
+    *counts_out = q;
+    return DVAE_OK;
+}
+
 extern "C" void dvae_batch_destroy(void* handle) { delete (PackedBatch*)handle; }

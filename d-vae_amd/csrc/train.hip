@@ -112,9 +112,8 @@ struct Side {
     // third stream: the weight-gradient chunks of the encoder's backward chains (both other streams walk a chain there)
     hipStream_t aux = nullptr;
     hipEvent_t aux_ev = nullptr, aux_join = nullptr;
-    bool aux_open = false;  // work enqueued on aux since the last join_aux
     unsigned long last_use = 0;
-    bool forked = false;  // per call: set by fork_side, cleared by join_side (SideGuard joins what an error path left open)
+    int users = 0;  // calls in progress that hold this entry (under g_side_mu): an entry in use is never recycled
 };
 constexpr int SIDE_CAP = 64;
 static std::mutex g_side_mu;
@@ -122,7 +121,26 @@ static Side* g_sides[SIDE_CAP];
 static int g_nsides = 0;
 static unsigned long g_side_clock = 0;
 
-static int side_for_stream(hipStream_t caller, Side** out) {
+// One call's hold on a Side entry.  The per-call state (is a fork open? is work pending on the aux stream?) lives HERE,
+// on the caller's stack, not in the shared entry: two host threads that share a caller stream (e.g. the null stream)
+// share the entry's streams and events -- their records land on the one stream in issue order, so a wait can only pick
+// up a later point of the same stream: over-ordered, never under-ordered -- but neither can clear or join the other's
+// state.  The destructor joins what an error path left open (whatever was enqueued on the side streams stays ordered
+// before the caller's later work) and releases the entry.
+struct SideGuard {
+    Side* sd = nullptr;
+    hipStream_t main = nullptr;
+    bool forked = false;    // set by fork_side, cleared by join_side
+    bool aux_open = false;  // work enqueued on aux since the last join_aux
+    explicit SideGuard(hipStream_t m) : main(m) {}
+    SideGuard(const SideGuard&) = delete;
+    SideGuard& operator=(const SideGuard&) = delete;
+    ~SideGuard();
+};
+
+static int side_acquire(SideGuard& g) {
+    if (g.sd) return DVAE_OK;
+    hipStream_t caller = g.main;
     int dev = 0;
     DVAE_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_side_mu);
@@ -132,10 +150,10 @@ static int side_for_stream(hipStream_t caller, Side** out) {
     if (!sd) {
         if (g_nsides < SIDE_CAP) {
             sd = g_sides[g_nsides++] = new Side();
-        } else {  // recycle the entry that has been idle longest (its stream keeps running what it holds)
-            sd = g_sides[0];
-            for (int i = 1; i < g_nsides; ++i)
-                if (g_sides[i]->last_use < sd->last_use) sd = g_sides[i];
+        } else {  // recycle the idle entry that has been idle longest (its stream keeps running what it holds)
+            for (int i = 0; i < g_nsides; ++i)
+                if (g_sides[i]->users == 0 && (!sd || g_sides[i]->last_use < sd->last_use)) sd = g_sides[i];
+            DVAE_REQUIRE(sd != nullptr, "more than %d caller streams with calls in progress at once", SIDE_CAP);
             int cur = dev;
             if (sd->dev != cur) DVAE_HIP(hipSetDevice(sd->dev));
             (void)hipStreamDestroy(sd->stream);
@@ -168,46 +186,44 @@ static int side_for_stream(hipStream_t caller, Side** out) {
         DVAE_HIP(hipEventCreateWithFlags(&sd->aux_join, evf));
     }
     sd->last_use = ++g_side_clock;
-    *out = sd;
+    sd->users++;
+    g.sd = sd;
     return DVAE_OK;
 }
-static int fork_side(Side* sd, hipStream_t main) {
-    DVAE_HIP(hipEventRecord(sd->fork, main));
-    DVAE_HIP(hipStreamWaitEvent(sd->stream, sd->fork, 0));
-    sd->forked = true;
+static int fork_side(SideGuard& g) {
+    DVAE_HIP(hipEventRecord(g.sd->fork, g.main));
+    DVAE_HIP(hipStreamWaitEvent(g.sd->stream, g.sd->fork, 0));
+    g.forked = true;
     return DVAE_OK;
 }
-static int join_side(Side* sd, hipStream_t main) {
-    sd->forked = false;
-    DVAE_HIP(hipEventRecord(sd->join, sd->stream));
-    DVAE_HIP(hipStreamWaitEvent(main, sd->join, 0));
+static int join_side(SideGuard& g) {
+    g.forked = false;
+    DVAE_HIP(hipEventRecord(g.sd->join, g.sd->stream));
+    DVAE_HIP(hipStreamWaitEvent(g.main, g.sd->join, 0));
     return DVAE_OK;
 }
 // aux stream: `after(producer)` orders everything enqueued on aux from now on behind what `producer` holds now
 // (a stream wait captures the event's latest record at the time of the call, so one event serves every hand-off)
-static int aux_after(Side* sd, hipStream_t producer) {
-    DVAE_HIP(hipEventRecord(sd->aux_ev, producer));
-    DVAE_HIP(hipStreamWaitEvent(sd->aux, sd->aux_ev, 0));
-    sd->aux_open = true;
+static int aux_after(SideGuard& g, hipStream_t producer) {
+    DVAE_HIP(hipEventRecord(g.sd->aux_ev, producer));
+    DVAE_HIP(hipStreamWaitEvent(g.sd->aux, g.sd->aux_ev, 0));
+    g.aux_open = true;
     return DVAE_OK;
 }
-static int join_aux(Side* sd, hipStream_t main) {
-    if (!sd->aux_open) return DVAE_OK;
-    sd->aux_open = false;
-    DVAE_HIP(hipEventRecord(sd->aux_join, sd->aux));
-    DVAE_HIP(hipStreamWaitEvent(main, sd->aux_join, 0));
+static int join_aux(SideGuard& g) {
+    if (!g.aux_open) return DVAE_OK;
+    g.aux_open = false;
+    DVAE_HIP(hipEventRecord(g.sd->aux_join, g.sd->aux));
+    DVAE_HIP(hipStreamWaitEvent(g.main, g.sd->aux_join, 0));
     return DVAE_OK;
 }
-// Joins the side stream when an entry point leaves through an error return between a fork and its join:
-// whatever was enqueued on the side stream stays ordered before the caller's later work.
-struct SideGuard {
-    Side*& sd;
-    hipStream_t main;
-    ~SideGuard() {
-        if (sd && sd->forked) join_side(sd, main);
-        if (sd && sd->aux_open) join_aux(sd, main);
-    }
-};
+SideGuard::~SideGuard() {
+    if (!sd) return;
+    if (forked) join_side(*this);
+    if (aux_open) join_aux(*this);
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    sd->users--;
+}
 
 struct EncWs {
     float *agg[2], *gates[2], *ghn[2], *hs[2], *gm[2], *msg[2];
@@ -347,9 +363,9 @@ using namespace dvae;
 
 extern "C" int dvae_debug_side_stream(void* caller_stream, void** side_stream) {
     DVAE_REQUIRE(side_stream != nullptr, "dvae_debug_side_stream: null output");
-    Side* sd = nullptr;
-    DVAE_TRY(side_for_stream((hipStream_t)caller_stream, &sd));
-    *side_stream = (void*)sd->stream;
+    SideGuard g((hipStream_t)caller_stream);
+    DVAE_TRY(side_acquire(g));
+    *side_stream = (void*)g.sd->stream;
     return DVAE_OK;
 }
 
@@ -479,7 +495,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     DVAE_REQUIRE(blob && pw && ws && mu && logvar, "dvae_encode_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
-    set_mode(d, L, pw);
+    ModeGuard mode_guard(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB;
@@ -539,11 +555,11 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     const bool tiny = fused && chain_tiny_persist(d, c->B, dirs);
     const bool persist = tiny || chain_persist(d, c->B);
     const bool merged = !persist && fused && dirs == 2 && !d.bn && chain_merge_dirs();
-    Side* side = nullptr;
-    SideGuard side_guard{side, s};
+    SideGuard side_guard(s);
+    Side*& side = side_guard.sd;
     if (dirs == 2 && !merged && !persist) {
-        DVAE_TRY(side_for_stream(s, &side));
-        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(side_acquire(side_guard));
+        DVAE_TRY(fork_side(side_guard));
     }
     if (tiny) {
         TinyChainArgs a = {};
@@ -602,7 +618,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
             DVAE_TRY(level(0, step, s));
         }
     }
-    if (dirs == 2 && !merged && !persist) DVAE_TRY(join_side(side, s));
+    if (dirs == 2 && !merged && !persist) DVAE_TRY(join_side(side_guard));
     // graph state (models.py:704-718 / 1006-1027)
     DVAE_TRY(dvae_gather_sum_f32(w.hg, 2 * Hp, w.hs[0], Hp, bv.hgf_off, bv.hgf_idx, B, Hp, 0, s));
     const float* hgu = w.hg;
@@ -631,7 +647,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     DVAE_REQUIRE(blob && pw && ws && dmu && dlogvar && pg, "dvae_encode_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
-    set_mode(d, L, pw);
+    ModeGuard mode_guard(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     EncWs w = carve_enc(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, NZ2 = 2 * d.NZp;
@@ -642,17 +658,17 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     // csr_on_side: the type sort is a one-workgroup, latency-bound kernel that depends on the batch only; with
     // two directions it runs on the (still idle) side stream under the head of this function, and the main
     // stream picks it up with the join below, long after it has finished
-    Side* side = nullptr;
-    SideGuard side_guard{side, s};
+    SideGuard side_guard(s);
+    Side*& side = side_guard.sd;
     const bool tiny = fused && chain_tiny_persist(d, c->B, dirs);  // both directions' reverse chains as one persistent launch
     const bool merged = !tiny && fused && dirs == 2 && !d.bn && chain_merge_dirs();
     // per-level weight-gradient terms beside the chains: on the (idle) side stream with one direction, on a third
     // stream with two (both other streams walk a chain)
     const bool wbl = !d.bn && !merged && !tiny && wgrad_by_level(2);
-    if (dirs == 2 || wbl) DVAE_TRY(side_for_stream(s, &side));
+    if (dirs == 2 || wbl) DVAE_TRY(side_acquire(side_guard));
     hipStream_t wg_stream = wbl ? (dirs == 2 ? side->aux : side->stream) : nullptr;
     if (dirs == 2) {
-        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(fork_side(side_guard));
         DVAE_TRY(dvae_type_csr(bv.types, nB, nullptr, 0, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40,
                                side->stream));
     }
@@ -734,8 +750,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                                3 * Hp, Hp, 1, s));
         if (wbl) {
             // final now: d gh of this level; d gm of the level processed next (fused: the tail above) or of this one
-            if (dirs == 2) DVAE_TRY(aux_after(side, s));
-            else DVAE_TRY(fork_side(side, s));
+            if (dirs == 2) DVAE_TRY(aux_after(side_guard, s));
+            else DVAE_TRY(fork_side(side_guard));
             if (step > 0)  // (the pass's first level has h_prev = 0: no term)
                 DVAE_TRY(gru_whh_wgrad(d, L, k, pg, w.dgh[k], w.agg[k], r0, r0 + B, wg_stream, wbl_split()));
             const int sg = fused ? step - 1 : step;  // forward-pass step of the level whose d gm is final
@@ -764,9 +780,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     };
     // as in the forward pass: two streams, enqueued level by level in turn
     // (as in the forward pass: optionally both directions of a level as one grid)
-    if (dirs == 2) DVAE_TRY(join_side(side, s));  // the type sort (csr_on_side)
+    if (dirs == 2) DVAE_TRY(join_side(side_guard));  // the type sort (csr_on_side)
     if (dirs == 2 && !merged && !tiny) {
-        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(fork_side(side_guard));
         DVAE_TRY(begin_dir(1, side->stream));
     }
     DVAE_TRY(begin_dir(0, s));
@@ -786,7 +802,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
         a.poison = pg + L.whh[0];  // a timed-out wait turns the gradients NaN (the weight-gradient products below add to it)
         DVAE_TRY(tiny_chain_bwd(a, s));
-        if (dirs == 2) DVAE_TRY(fork_side(side, s));  // the two directions' weight gradients on two streams
+        if (dirs == 2) DVAE_TRY(fork_side(side_guard));  // the two directions' weight gradients on two streams
     } else if (d.bn) {
         if (dirs == 2) DVAE_TRY(run_dir_bn(1, side->stream));
         DVAE_TRY(run_dir_bn(0, s));
@@ -821,7 +837,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             if (step < n - 1) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_GRU_BWD, gb, 2, B, Hp, s));
             if (step > 0) DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, da, 2, B, Hp, s));
         }
-        DVAE_TRY(fork_side(side, s));
+        DVAE_TRY(fork_side(side_guard));
     } else {
         for (int step = n - 1; step >= 0; --step) {
             if (dirs == 2) DVAE_TRY(level(1, step, side->stream));
@@ -830,8 +846,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
     }
     if (dirs == 2) DVAE_TRY(end_dir(1, side->stream));
     DVAE_TRY(end_dir(0, s));
-    if (dirs == 2 || (side && side->forked)) DVAE_TRY(join_side(side, s));
-    if (side) DVAE_TRY(join_aux(side, s));
+    if (dirs == 2 || side_guard.forked) DVAE_TRY(join_side(side_guard));
+    if (side) DVAE_TRY(join_aux(side_guard));
     return DVAE_OK;
 }
 
@@ -849,7 +865,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_REQUIRE(!training || eps, "dvae_loss_forward: training mode needs the normal draw eps");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
-    set_mode(d, L, pw);
+    ModeGuard mode_guard(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp;
@@ -865,9 +881,9 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // batch: B = 32 26.2 k vs 29.9 k DAGs/s, 128 93.3 k vs 98.2 k, 256 149.6 k vs 152.2 k, 512 200.4 k vs 197.3 k;
     // DVAE_BY_LEVEL=2 forces the per-level form at every size)
     const bool by_level = !d.bn && c->level_major != 0 && (by_level_knob == 2 || (by_level_knob == 1 && c->B > 256));
-    Side* side = nullptr;
-    SideGuard side_guard{side, s};
-    if (by_level) DVAE_TRY(side_for_stream(s, &side));
+    SideGuard side_guard(s);
+    Side*& side = side_guard.sd;
+    if (by_level) DVAE_TRY(side_acquire(side_guard));
     // small batches (launch-bound): one single-workgroup launch does the accumulators' and the tables' zero rows'
     // zeroing too; larger ones keep the multi-workgroup kernel (a lone workgroup walking 64 k elements was measured
     // 0.4 % slower on the cfg-2 step than the launches it saved), which still zeroes the two rows
@@ -926,7 +942,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 // (graph state after v + 1 vertices) run now on the side stream, small launches that
                 // fill the CUs the latency-bound chain leaves idle (as the second encoder direction does).
                 hipStream_t s2 = side->stream;
-                DVAE_TRY(fork_side(side, s));
+                DVAE_TRY(fork_side(side_guard));
                 DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.w1a, Hp, nullptr, w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2));
                 DVAE_TRY(dvae_gather_sum_f32(w.vs + r0 * Hp, Hp, w.st, Hp, bv.vs_off + r0, bv.vs_idx, B, Hp, 0, s2));
                 DVAE_TRY(lin_fwd(w.vs + r0 * Hp, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1 + r0 * d.HVp, d.HVp, B, d.HVp,
@@ -968,7 +984,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
     DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
-    if (by_level) DVAE_TRY(join_side(side, s));
+    if (by_level) DVAE_TRY(join_side(side_guard));
     DVAE_TRY(pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t, pw + L.be1,
                           pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, nblk, c->NP, HEp, w.sums, tickets,
                           beta, out3, s, (pair_group_knob() && c->B >= w.dw2_blocks / 2) ? c->NP / c->B : 0));
@@ -994,7 +1010,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_REQUIRE(blob && pw && ws && mu && logvar && g3 && dmu && dlogvar && pg, "dvae_loss_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const PackedLayout L = make_layout(d);
-    set_mode(d, L, pw);
+    ModeGuard mode_guard(d, L, pw);
     const BatchView bv = bind_batch(*c, blob);
     DecWs w = carve_dec(d, *c, ws);
     const int B = c->B, n = d.n, Hp = d.Hp, nB = c->nB, PT = c->PT, HEp = d.HEp, NST = nB + PT;
@@ -1022,14 +1038,14 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     }
     // The predictors' weight gradients depend only on what is already computed; they run on the
     // side stream while the main stream continues into the (latency-bound) state chain.
-    Side* side = nullptr;
-    SideGuard side_guard{side, s};
-    DVAE_TRY(side_for_stream(s, &side));
+    SideGuard side_guard(s);
+    Side*& side = side_guard.sd;
+    DVAE_TRY(side_acquire(side_guard));
     DVAE_HIP(hipMemsetAsync(w.dst, 0, sizeof(float) * (size_t)NST * Hp, s));
     // vertex-type predictor, data path (main stream)
     // (the ReLU backward of add_vertex's hidden layer is the product's epilogue: masked by v1 > 0)
     DVAE_TRY(lin_dgrad(w.dlogits_s, d.Tp, pw + L.wv2, d.HVp, w.dv1, d.HVp, nullptr, c->R, d.Tp, d.HVp, 0, s, w.v1));
-    DVAE_TRY(fork_side(side, s));
+    DVAE_TRY(fork_side(side_guard));
     {
         hipStream_t s2 = side->stream;
         // rows sorted by vertex type (off at xoh[0..T], idx from xoh[40]) for the GRU's input-side gradients, which
@@ -1040,6 +1056,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
+        DVAE_LAUNCH_CHECK();
         DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2, NST));
         DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2, NST));
         if (d.bn) DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s2));
@@ -1090,7 +1107,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             DVAE_TRY(tiny_chain_bwd(a, s));
         }
         if (wbl) {  // the partial rows' d gh is final: their term of dWhh starts the side stream's run beside the chain
-            DVAE_TRY(fork_side(side, s));
+            DVAE_TRY(fork_side(side_guard));
             DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2));
         }
         for (int v = n - 1; v >= 0 && !tiny; --v) {
@@ -1127,7 +1144,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             if (wbl) {
                 // final now: d gh of vertex v, and d gm of vertex v - 1 (fused: the tail above) or v (unfused: this iteration)
                 const int vg = fused ? v - 1 : v;
-                DVAE_TRY(fork_side(side, s));
+                DVAE_TRY(fork_side(side_guard));
                 DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + B, s2, wbl_split()));
                 if (vg >= 0 && vg < n - 1)  // (d gm of the last vertex is zero: no message leaves it)
                     DVAE_TRY(lin_wgrad(w.dgm + (size_t)vg * B * 2 * Hp, 2 * Hp, w.st + (size_t)vg * B * Hp, Hp, nullptr,
@@ -1136,7 +1153,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         }
     }
     // the GRU's remaining weight gradients go to the side stream, behind the predictors' and the per-level terms
-    DVAE_TRY(fork_side(side, s));
+    DVAE_TRY(fork_side(side_guard));
     const bool wbl_done = !d.bn && wgrad_by_level() && wbl_size_ok(d, B) && !(fused && chain_tiny_persist(d, B));
     if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream));
     else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
@@ -1151,6 +1168,6 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         if (!wbl_done) DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
     }
-    DVAE_TRY(join_side(side, s));
+    DVAE_TRY(join_side(side_guard));
     return DVAE_OK;
 }

@@ -302,6 +302,11 @@ int dvae_unpack_grads(const dvae_model_desc* m, const float* packed_w, const flo
  * gradient buffer is left at zero (the optimizer.zero_grad() of the next step, train.py:225, in the same pass). */
 int dvae_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                        float eps, int32_t step, int32_t zero_grad, void* stream);
+/* The same update with the learning rate and the step count kept in DEVICE memory (lr_dev: one float; step_dev: one
+ * int32 = steps taken so far, incremented by the call), so that the enqueued work carries no per-step host scalar
+ * and a captured train step can be replayed as it is; torch.optim.Adam's `capturable=True` is the counterpart. */
+int dvae_adam_step_dev_f32(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
+                           float beta2, float eps, int32_t* step_dev, int32_t zero_grad, void* stream);
 
 /* ---------------------------------------------------------------------------
  * DAG batching (host).  Replaces models.py:631-632 (_collate_fn), the per-vertex
@@ -333,6 +338,18 @@ int dvae_batch_create(int32_t B, int32_t max_n, int32_t nvt, int32_t start_type,
                       dvae_batch_counts* counts);
 /* writes the index blob (counts.total_ints int32) into HOST memory `out` */
 int dvae_batch_export(void* handle, int32_t* out, int64_t out_ints);
+/* Shape-stable export for callers that replay ONE recorded launch sequence (a captured HIP graph of the train step,
+ * train.py:224-253) over many batches.  The counts that depend on the batch's edges -- E, PT, PL, NB, CH -- are
+ * raised to `caps` with inert padding entries (empty lists, rows no pair refers to, empty backward chunks; see
+ * csrc/packer.cpp), so every batch of the same (B, max_n, nvt, kind, caps) yields the same `counts_out`, blob
+ * layout, workspace sizes, grids and kernel arguments, and the same results as the plain export.  Requires every
+ * graph to have max_n vertices; a batch above a cap is refused (negative return): export it plainly instead.
+ * No counterpart in the reference (its batching is a Python list, models.py:631-632). */
+typedef struct dvae_batch_caps {
+    int32_t E, PT, PL, NB, CH;
+} dvae_batch_caps;
+int dvae_batch_export_padded(void* handle, const dvae_batch_caps* caps, int32_t* out, int64_t out_ints,
+                             dvae_batch_counts* counts_out);
 void dvae_batch_destroy(void* handle);
 
 /* ---------------------------------------------------------------------------
@@ -398,8 +415,13 @@ int dvae_decode(const dvae_model_desc* m, int32_t B, const float* pw, float* ws,
  * object, one copy per GPU, held until the process ends.  The call allocates nothing and rejects a
  * (model, B) whose dvae_decode_ws_floats exceeds that size (negative return, text in
  * dvae_last_error()): e.g. B <= 263 at max_n = 8, hs = 501; B <= 20 at max_n = 64, hs = 1024.
- * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
- * threads) race; order them on one stream. */
+ * All calls on one GPU share that GPU's array, so calls must not overlap on one GPU.  Calls on ONE
+ * stream are ordered by the stream.  A call that arrives on another stream while the previous call's
+ * work has not finished is REFUSED (negative return, "still running" in dvae_last_error()) instead
+ * of racing: each call leaves an event behind its work and the next one queries it.  (Set-up on the
+ * first call on a device: hipGetSymbolAddress and one hipEventCreate; no call allocates device
+ * memory.  Under stream capture no event is left or queried: the order of captured calls is the
+ * capturing caller's graph.) */
 #define DVAE_DECODE_STATIC_FLOATS (8 * 1024 * 1024)
 int64_t dvae_decode_static_max_floats(void);
 int dvae_decode_static(const dvae_model_desc* m, int32_t B, const float* pw, const float* z, int32_t stochastic,

@@ -6,7 +6,8 @@ in each of their modes: 8-wave workgroups, 4-wave workgroups, both encoder direc
 encoder's forward chain as one persistent launch, the 32-row kernels of small levels and the 16-row kernels of the
 smallest (each forced for every size; the 16-row kernels once as per-level launches and once as the persistent
 small-batch chains of csrc/chain_persist.hip, which are the default up to 128 rows), and the loss forward's per-level side-stream products and the decoder's per-level
-weight-gradient terms, which the step uses above 256 / 64 graphs only.
+weight-gradient terms, which the step uses above 256 / 64 graphs only (once more with the ENCODER's per-level terms on
+the third, "aux" stream: off by default, measured slower, kept as a knob).
 (The knobs are read once per process, hence the child process; one at a time, GPU use stays at 2 processes.)"""
 import os
 import subprocess
@@ -29,9 +30,11 @@ BIG = {"DVAE_CHAIN_SMALL_M": "0", "DVAE_CHAIN_TINY_M": "0"}
                                    dict(BIG, DVAE_CHAIN_PERSIST="1"), {"DVAE_CHAIN_SMALL_M": "4096", "DVAE_CHAIN_TINY_M": "0"},
                                    {"DVAE_CHAIN_SMALL_M": "4096", "DVAE_CHAIN_TINY_M": "4096", "DVAE_CHAIN_TINY_PERSIST": "0"},
                                    {"DVAE_CHAIN_SMALL_M": "4096", "DVAE_CHAIN_TINY_M": "4096", "DVAE_CHAIN_TINY_PERSIST": "1"},
-                                   {"DVAE_BY_LEVEL": "2", "DVAE_WGRAD_BY_LEVEL": "9", "DVAE_CHAIN_TINY_PERSIST": "0"}],
+                                   {"DVAE_BY_LEVEL": "2", "DVAE_WGRAD_BY_LEVEL": "9", "DVAE_CHAIN_TINY_PERSIST": "0"},
+                                   {"DVAE_BY_LEVEL": "2", "DVAE_WGRAD_BY_LEVEL": "11", "DVAE_CHAIN_TINY_PERSIST": "0"}],
                          ids=["8-wave", "4-wave", "merged-directions", "persistent-encoder", "small-level-kernels",
-                              "tiny-level-kernels", "tiny-persistent-chains", "per-level-side-stream"])
+                              "tiny-level-kernels", "tiny-persistent-chains", "per-level-side-stream",
+                              "per-level-aux-stream"])
 def test_parity_with_fused_level_kernels_forced(extra):
     env = dict(os.environ, **FORCED, **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",

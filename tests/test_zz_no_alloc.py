@@ -82,3 +82,50 @@ def test_decode_static_rejects_what_does_not_fit():
                                 out.data_ptr(), out.data_ptr(), out.data_ptr(),
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0 and b"static scratch holds" in lib.dvae_last_error()
+
+
+def test_decode_static_allocates_nothing_and_refuses_overlapping_calls():
+    """(a) The property the entry point exists for: after the one-time set-up (symbol look-up on the first call on a
+    device) a call takes no device memory -- free memory as the driver reports it is the same before and after a call
+    whose inputs and outputs were allocated beforehand.  (b) Calls that overlap on one GPU share the array: a call on
+    ANOTHER stream while the previous one is still running is refused with an error instead of racing; calls on one
+    stream are ordered by the stream and pass."""
+    lib = L.load()
+    dev = torch.device("cuda")
+    model = make_model("DVAE", dict(max_n=8, nvt=8, START_TYPE=0, END_TYPE=1, hs=72, nz=10, bidirectional=0), 7).cuda().eval()
+    B, n = 64, model.max_n
+    z = torch.randn(B, model.nz, device=dev)
+    types = torch.zeros(B, n, dtype=torch.int32, device=dev)
+    pmask = torch.zeros(B, n, dtype=torch.int64, device=dev)
+    n_g = torch.zeros(B, dtype=torch.int32, device=dev)
+    pw = model._packed_weights()
+
+    def call(stream):
+        return lib.dvae_decode_static(C.byref(model._desc), B, pw.data_ptr(), z.data_ptr(), 0, None, None, types.data_ptr(),
+                                      pmask.data_ptr(), n_g.data_ptr(), C.c_void_p(stream.cuda_stream))
+
+    main = torch.cuda.current_stream()
+    L.check(call(main), "dvae_decode_static")  # set-up happens here at the latest
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    L.check(call(main), "dvae_decode_static")
+    L.check(call(main), "dvae_decode_static")  # back to back on ONE stream: ordered, accepted
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, "dvae_decode_static changed the device's free memory by %d bytes" % (free0 - free1)
+    ref = n_g.clone()
+
+    # overlap: keep the main stream busy for a few milliseconds in front of a call, then call on a second stream
+    other = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=dev)
+    out = torch.empty_like(big)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        torch.mm(big, big, out=out)
+    L.check(call(main), "dvae_decode_static")
+    rc = call(other)
+    assert rc != 0 and b"still running" in lib.dvae_last_error()
+    torch.cuda.synchronize()
+    L.check(call(other), "dvae_decode_static")  # the earlier call has finished: accepted
+    torch.cuda.synchronize()
+    assert torch.equal(n_g, ref)
