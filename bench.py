@@ -55,6 +55,11 @@ def parse_args(argv=None):
     ap.add_argument("--allreduce", default="overlap", choices=["overlap", "after"],
                     help="N > 1: overlap = the decoder-only part of the gradient buffer is all-reduced from inside "
                          "backward(), beside the encoder's backward (default); after = one all-reduce after backward()")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the train step from one captured HIP graph over shape-stable (padded) batches "
+                         "(harness.GraphedTrainStep).  auto = off: measured on cfg 1 (profiles/r03_graph_replay_cfg1.txt) a "
+                         "replay costs the host 0.08 ms instead of 0.73 ms per step but the GPU 0.86 instead of 0.82 ms, "
+                         "and the GPU is what bounds the step on this box; 'on' is for hosts that cannot keep up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -401,12 +406,14 @@ def main():
     # Adam as one launch over the flat parameter buffer: the update rule of train.py:174
     reducer = dvae_amd.dist.GradSumReducer(model)
     reducer.overlap = args.allreduce == "overlap"
-    opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer)
+    B = int(os.environ.get("DVAE_BENCH_B", cfg["B"]))  # diagnostic override (batch-size sweeps); not a bench line
+    use_graph = world == 1 and os.environ.get("DVAE_FORCE_COLLECTIVE") != "1" and \
+        args.graph == "on"
+    opt = dvae_amd.optim.FlatAdam(model, lr=1e-4, reducer=reducer, capturable=use_graph)
 
     # pre-packed batches.  weak: every rank owns B graphs per step (its own synthetic draw);
     # strong: every rank owns its contiguous ceil-split chunk (util.py:566-572) of the same global batch.
     # Either way eps is the rank's row range of ONE global normal draw (N-rank parity rule).
-    B = int(os.environ.get("DVAE_BENCH_B", cfg["B"]))  # diagnostic override (batch-size sweeps); not a bench line
     n_batches = cfg.get("n_batches", 4)
     strong = args.scaling == "strong"
     if strong:
@@ -420,10 +427,20 @@ def main():
     B_rank = hi - lo
     if B_rank <= 0:
         raise SystemExit("rank %d has no graphs (global batch %d over %d ranks)" % (rank, Bg, world))
-    model._collate_fn(graphs[0])  # first call: library load, allocator warm-up
+    caps = None
+    if use_graph:
+        # shape-stable packing: caps from the statistics of the data the batches are drawn from (here: all of them)
+        allg = graphs[0]
+        for ga in graphs[1:]:
+            allg = dvae_amd.GraphArrays(np.concatenate([allg.types, ga.types]), np.concatenate([allg.pred_mask, ga.pred_mask]),
+                                        np.concatenate([allg.n_vertices, ga.n_vertices]), allg.max_n)
+        caps = dvae_amd.batching.padding_caps(allg, B_rank, cfg["nvt"])
+        use_graph = caps is not None
+    graphed = dvae_amd.harness.GraphedTrainStep(model, opt) if use_graph else None
+    model._collate_fn(graphs[0], caps)  # first call: library load, allocator warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    batches = [model._collate_fn(ga) for ga in graphs]  # host packer (C++) + the index blob's copy to the GPU
+    batches = [model._collate_fn(ga, caps) for ga in graphs]  # host packer (C++) + the index blob's copy to the GPU
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t0) * 1e3 / n_batches
     eps = []
@@ -437,6 +454,8 @@ def main():
 
     def step(i, timed=False, events=None):
         b = batches[i % n_batches]
+        if graphed is not None:
+            return graphed(b, eps=eps[i % n_batches])[0]
         reducer.zero()
         mu, logvar = model.encode(b)
         loss, _, _ = model.loss(mu, logvar, b, eps=eps[i % n_batches])
@@ -557,7 +576,10 @@ def main():
                        "encode_bwd_ms": enc_bwd,                # {"overlap": with the early part in flight, "after": without}
                        "pack_ms_per_batch": pack_ms, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                        "host_enqueue_ms_per_step_unblocked": host_unblocked_ms,
-                       "launches_per_step": launches,  # the library's kernel launches (its memsets / copies and torch's own are not counted)
+                       "launches_per_step": launches,  # the library's kernel launches ENQUEUED BY THE HOST per step (its memsets / copies and torch's own are not counted; replays of a captured step enqueue none)
+                       "graph": ({"replays": graphed.replays, "eager_steps": graphed.eager_steps,
+                                  "padded_batches": sum(1 for b in batches if b.padded), "batches": len(batches)}
+                                 if graphed is not None else None),
                        "loss_last_step": loss_global},
             "roofline": roof_line,
             "roofline_gemm": gemm_line,
@@ -571,6 +593,8 @@ def main():
                                            "achieved": exec_flop_per_step / (dt / args.steps) / 1e12,
                                            "frac": exec_flop_per_step / (dt / args.steps) / 1e12 / peak}},
         }
+        if graphed is not None:
+            out["config"]["workload"] += "; step replayed from one captured HIP graph over shape-stable (padded) batches"
         by_kernel = roofline_by_kernel() if (args.config == "cfg2" and not bf16) else None
         if by_kernel is not None:
             out["roofline_by_kernel"] = by_kernel

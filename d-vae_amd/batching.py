@@ -112,10 +112,48 @@ def _copy_stream(device):
     return _COPY_STREAMS[key]
 
 
-class DAGBatch(object):
-    """A packed batch: host arrays + the device index blob the kernels read."""
+def padding_caps(arrays, batch_size, nvt, sigmas=6.0):
+    """Caps for shape-stable (padded) batches of `batch_size` graphs drawn from the data set `arrays`
+    (include/dvae_hip.h: dvae_batch_export_padded): every such batch then has the same counts, blob layout and launch
+    sequence, which is what replaying one captured train step needs (harness.GraphedTrainStep).
+    The counts that cost COMPUTE when padded -- partial-state rows PT and EB-table rows NB -- are capped
+    statistically: batch sums of per-graph contributions, mean + `sigmas` standard deviations of a random batch
+    (clipped to the worst case), so padding adds a few per cent of rows; a batch above a cap falls back to the plain
+    export (and the eager step).  E, PL and CH only size index arrays / empty chunks: worst case.
+    Returns None when the data set does not qualify (graphs of different sizes)."""
+    n = arrays.max_n
+    if len(arrays) == 0 or not np.all(arrays.n_vertices == n):
+        return None
+    m = arrays.pred_mask
+    indeg = np.zeros(m.shape, np.int64)
+    for u in range(n):
+        indeg += ((m >> np.uint64(u)) & np.uint64(1)).astype(np.int64)
+    part = np.maximum(indeg - 1, 0).sum(1)                                   # partial rows per graph
+    full = ((indeg[:, 1:] >= 1) & ((m[:, 1:] & np.uint64(1)) == 0)).sum(1)   # slot rows the EB table reads
+    B = int(batch_size)
 
-    def __init__(self, arrays, nvt, start_type, is_bn, device):
+    def cap(x, worst):
+        v = B * float(x.mean()) + sigmas * (B ** 0.5) * float(x.std()) + 1.0
+        return int(min(np.ceil(v), B * worst))
+
+    pairs = n * (n - 1) // 2
+    chunk = 64 if n > 16 else 16
+    PT = nvt + cap(part, (n - 1) * (n - 2) // 2)
+    NB = nvt + cap(part + full, (n - 1) * (n - 2) // 2 + (n - 1))
+    caps = _lib.BatchCaps()
+    caps.E = B * pairs
+    caps.PT = PT
+    caps.PL = B * sum(v * (v - 1) // 2 for v in range(1, n))
+    caps.NB = NB
+    caps.CH = NB + nvt + (B * pairs + chunk - 1) // chunk
+    return caps
+
+
+class DAGBatch(object):
+    """A packed batch: host arrays + the device index blob the kernels read.
+    `caps` (padding_caps): export shape-stable -- `self.padded` tells whether the batch fitted the caps."""
+
+    def __init__(self, arrays, nvt, start_type, is_bn, device, caps=None):
         lib = _lib.load()
         self.arrays = arrays
         self.B = len(arrays)
@@ -130,12 +168,29 @@ class DAGBatch(object):
                                          _lib.ptr(arrays.types), _lib.ptr(arrays.pred_mask),
                                          _lib.ptr(arrays.n_vertices), C.byref(handle), C.byref(counts)),
                    "dvae_batch_create")
+        self.padded = False
         try:
             self.device = torch.device(device)
             on_gpu = self.device.type == "cuda"
-            # pinned staging: the copy below is then a true asynchronous DMA instead of a staged pageable copy
-            host = torch.empty(int(counts.total_ints), dtype=torch.int32, pin_memory=on_gpu)
-            _lib.check(lib.dvae_batch_export(handle, host.data_ptr(), counts.total_ints), "dvae_batch_export")
+            host = None
+            if caps is not None:
+                # upper bound of the padded blob: the plain blob + the padding of the five capped counts (each array
+                # that grows is one of 4 index arrays of E, 3 of PL, 3 of PT, 1 of NB, 2 of CH entries; + alignment)
+                pc = _lib.BatchCounts()
+                grow = (4 * max(0, caps.E - counts.E) + 3 * max(0, caps.PL - counts.PL) + 3 * max(0, caps.PT - counts.PT) +
+                        max(0, caps.NB - counts.NB) + 2 * max(0, caps.CH - counts.CH) + 256)
+                host = torch.empty(int(counts.total_ints) + grow, dtype=torch.int32, pin_memory=on_gpu)
+                rc = lib.dvae_batch_export_padded(handle, C.byref(caps), host.data_ptr(), host.numel(), C.byref(pc))
+                if rc == 0:
+                    counts = pc
+                    host = host[:int(pc.total_ints)]
+                    self.padded = True
+                else:
+                    host = None  # above a cap (or graphs of different sizes): plain export
+            if host is None:
+                # pinned staging: the copy below is then a true asynchronous DMA instead of a staged pageable copy
+                host = torch.empty(int(counts.total_ints), dtype=torch.int32, pin_memory=on_gpu)
+                _lib.check(lib.dvae_batch_export(handle, host.data_ptr(), counts.total_ints), "dvae_batch_export")
         finally:
             lib.dvae_batch_destroy(handle)
         self.counts = counts

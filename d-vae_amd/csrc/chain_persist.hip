@@ -140,6 +140,8 @@ __global__ __launch_bounds__(512) void tiny_chain_fwd_kernel(TinyChainArgs a) {
     const int ns = Hp / 16;
     unsigned* cnt = a.sync + ((size_t)pass * tiles_y + rt) * 32;
 
+    if (a.zero_next && blockIdx.x == 0)  // the counters of the pass's next launch (visible to it across the kernel boundary)
+        for (int i = threadIdx.x; i < TINY_CHAIN_SYNC_WORDS; i += 512) a.zero_next[i] = 0u;
     float4 wr[NS][3], wg[NS][2];
     load_w_kcontig<NS, 3>(wr, e.whh, Hp, Hp, n0 + li, ns, kq, kg);
     load_w_kcontig<NS, 2>(wg, e.wgm, Hp, Hp, n0 + li, ns, kq, kg);
@@ -440,7 +442,7 @@ int tiny_chain_fwd(const TinyChainArgs& a, hipStream_t s) {
 
 int tiny_chain_bwd(const TinyChainArgs& a, hipStream_t s) {
     DVAE_TRY(tiny_chain_check(a));
-    DVAE_HIP(hipMemsetAsync(a.sync, 0, sizeof(unsigned) * TINY_CHAIN_SYNC_WORDS, s));
+    if (!a.sync_is_zero) DVAE_HIP(hipMemsetAsync(a.sync, 0, sizeof(unsigned) * TINY_CHAIN_SYNC_WORDS, s));
     const dim3 grid((unsigned)(a.ndirs * (a.Hp / 16) * cdiv(a.B, 16))), block(512);
     switch (tiny_ns(a.Hp)) {
     case 1: hipLaunchKernelGGL(tiny_chain_bwd_kernel<1>, grid, block, 0, s, a); break;

@@ -171,9 +171,12 @@ struct TinyChainArgs {
     TinyChainDir d[2];
     const int* types;
     int B, Hp, n, ndirs;
-    unsigned* sync;    // TINY_CHAIN_SYNC_WORDS words; zeroed by the launcher
+    unsigned* sync;    // TINY_CHAIN_SYNC_WORDS words; zeroed by the launcher unless `sync_is_zero`
     unsigned* status;  // == sync + TINY_CHAIN_SYNC_WORDS - 64; != 0 after the launch: a wait timed out
     float* poison;     // nullable: receives + NaN when a wait times out
+    unsigned* zero_next;  // nullable: TINY_CHAIN_SYNC_WORDS words this launch zeroes for the pass's NEXT launch (the forward
+                          // launch prepares the backward launch's counters: one memset per pass and step instead of two)
+    int sync_is_zero;     // 1: `sync` was zeroed by the previous launch's zero_next
 };
 bool tiny_chain_fits(int B, int Hp, int passes);
 int tiny_chain_fwd(const TinyChainArgs& a, hipStream_t s);

@@ -132,12 +132,22 @@ __global__ __launch_bounds__(256) void copy_ops_kernel(CopyOps ops) {
         }
         return;
     }
-    for (int r = blockIdx.x; r < rows; r += COPY_WGS) {
-        const float* sp = o.src + (long)r * o.src_ld;
-        float* dp = o.dst + (long)r * o.dst_ld;
+    // four rows per trip: their (scalar, unaligned-row) loads are independent and go out together -- one row per trip
+    // left every trip waiting for its own load (pack of hs = 501: 18 -> 11 us; the batch-32 step runs three of these)
+    for (int r = blockIdx.x; r < rows; r += 4 * COPY_WGS) {
         for (int c = threadIdx.x; c < cols; c += 256) {
-            const float v = sp[c];
-            dp[c] = acc ? dp[c] + v : v;
+            float v[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = r + k * COPY_WGS;
+                v[k] = rr < rows ? o.src[(long)rr * o.src_ld + c] : 0.f;
+                d[k] = (acc && rr < rows) ? o.dst[(long)rr * o.dst_ld + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = r + k * COPY_WGS;
+                if (rr < rows) o.dst[(long)rr * o.dst_ld + c] = d[k] + v[k];
+            }
         }
     }
 }

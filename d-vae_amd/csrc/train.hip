@@ -132,15 +132,30 @@ struct SideGuard {
     hipStream_t main = nullptr;
     bool forked = false;    // set by fork_side, cleared by join_side
     bool aux_open = false;  // work enqueued on aux since the last join_aux
+    bool inline_mode = false;  // DVAE_SIDE_STREAMS=0: the "side" streams ARE the caller's stream
     explicit SideGuard(hipStream_t m) : main(m) {}
     SideGuard(const SideGuard&) = delete;
     SideGuard& operator=(const SideGuard&) = delete;
     ~SideGuard();
 };
 
+// DVAE_SIDE_STREAMS=0: no side streams at all -- every "side" launch goes to the caller's stream in issue order (a
+// linear launch sequence; A/B runs, and captured graphs without forks)
+static bool side_streams_on() {
+    static const int knob = [] { const char* v = getenv("DVAE_SIDE_STREAMS"); return v ? atoi(v) : 1; }();
+    return knob != 0;
+}
 static int side_acquire(SideGuard& g) {
     if (g.sd) return DVAE_OK;
     hipStream_t caller = g.main;
+    if (!side_streams_on()) {
+        thread_local Side inline_side;  // stream == aux == the caller's stream; no events are ever used
+        inline_side.caller = inline_side.stream = inline_side.aux = caller;
+        inline_side.users = 1 << 30;
+        g.sd = &inline_side;
+        g.inline_mode = true;
+        return DVAE_OK;
+    }
     int dev = 0;
     DVAE_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_side_mu);
@@ -191,6 +206,7 @@ static int side_acquire(SideGuard& g) {
     return DVAE_OK;
 }
 static int fork_side(SideGuard& g) {
+    if (g.inline_mode) return DVAE_OK;
     DVAE_HIP(hipEventRecord(g.sd->fork, g.main));
     DVAE_HIP(hipStreamWaitEvent(g.sd->stream, g.sd->fork, 0));
     g.forked = true;
@@ -198,6 +214,7 @@ static int fork_side(SideGuard& g) {
 }
 static int join_side(SideGuard& g) {
     g.forked = false;
+    if (g.inline_mode) return DVAE_OK;
     DVAE_HIP(hipEventRecord(g.sd->join, g.sd->stream));
     DVAE_HIP(hipStreamWaitEvent(g.main, g.sd->join, 0));
     return DVAE_OK;
@@ -205,20 +222,21 @@ static int join_side(SideGuard& g) {
 // aux stream: `after(producer)` orders everything enqueued on aux from now on behind what `producer` holds now
 // (a stream wait captures the event's latest record at the time of the call, so one event serves every hand-off)
 static int aux_after(SideGuard& g, hipStream_t producer) {
+    if (g.inline_mode) return DVAE_OK;
     DVAE_HIP(hipEventRecord(g.sd->aux_ev, producer));
     DVAE_HIP(hipStreamWaitEvent(g.sd->aux, g.sd->aux_ev, 0));
     g.aux_open = true;
     return DVAE_OK;
 }
 static int join_aux(SideGuard& g) {
-    if (!g.aux_open) return DVAE_OK;
+    if (!g.aux_open || g.inline_mode) return DVAE_OK;
     g.aux_open = false;
     DVAE_HIP(hipEventRecord(g.sd->aux_join, g.sd->aux));
     DVAE_HIP(hipStreamWaitEvent(g.main, g.sd->aux_join, 0));
     return DVAE_OK;
 }
 SideGuard::~SideGuard() {
-    if (!sd) return;
+    if (!sd || inline_mode) return;
     if (forked) join_side(*this);
     if (aux_open) join_aux(*this);
     std::lock_guard<std::mutex> lock(g_side_mu);
@@ -265,7 +283,7 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.d12 = b.take((size_t)c.B * 2 * d.NZp);
     w.dhgu = b.take((size_t)c.B * Hp);
     w.dhg = b.take((size_t)c.B * 2 * Hp);
-    w.sync = b.take(ENC_CHAIN_SYNC_WORDS);
+    w.sync = b.take(ENC_CHAIN_SYNC_WORDS);  // (>= 2 TINY_CHAIN_SYNC_WORDS: slot 0 forward, slot 1 backward launch)
     w.total = b.off;
     return w;
 }
@@ -319,7 +337,7 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dh0c = d.bn ? b.take((size_t)c.B * Hp) : nullptr;
     w.dz = b.take((size_t)c.B * d.NZp);
     w.gs = b.take(8);
-    w.sync = b.take(TINY_CHAIN_SYNC_WORDS);
+    w.sync = b.take(2 * TINY_CHAIN_SYNC_WORDS);  // slot 0: the forward launch, slot 1: the backward launch
     w.total = b.off;
     return w;
 }
@@ -483,6 +501,25 @@ static int wbl_split() {
     return knob;
 }
 
+// level-major batches (every graph full size: all of the reference's data sets) run the loss forward's per-level
+// predictor products beside the chain
+// (small batches: the per-level side-stream launches cost more host time -- a fork and three launches per level --
+// than their overlap gains, and batch 32 is bound by the host's enqueue rate; measured on the step, by level vs whole
+// batch: B = 32 26.2 k vs 29.9 k DAGs/s, 128 93.3 k vs 98.2 k, 256 149.6 k vs 152.2 k, 512 200.4 k vs 197.3 k;
+// DVAE_BY_LEVEL=2 forces the per-level form at every size)
+static bool loss_by_level(const Dims& d, const dvae_batch_counts& c) {
+    static const int by_level_knob = [] { const char* v = getenv("DVAE_BY_LEVEL"); return v ? atoi(v) : 1; }();
+    return !d.bn && c.level_major != 0 && (by_level_knob == 2 || (by_level_knob == 1 && c.B > 256));
+}
+// does dvae_loss_forward run the decoder's chain as ONE persistent launch?  (dvae_loss_backward asks too: that launch
+// also zeroes the counters of the backward pass's launch)
+static bool loss_fwd_tiny(const Dims& d, const dvae_batch_counts& c) {
+    return chain_fused(d, c.B) && !loss_by_level(d, c) && chain_tiny_persist(d, c.B);
+}
+static bool enc_fwd_tiny(const Dims& d, const dvae_batch_counts& c) {
+    return chain_fused(d, c.B) && chain_tiny_persist(d, c.B, d.bidir ? 2 : 1);
+}
+
 // =====================================================================================
 // encode
 // =====================================================================================
@@ -552,7 +589,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
     // host is still issuing the other one's launches.
     // (optional, DVAE_CHAIN_MERGE=1: both directions of a level as ONE grid on the caller's stream,
     // dvae_chain_level_batch, instead of two streams)
-    const bool tiny = fused && chain_tiny_persist(d, c->B, dirs);
+    const bool tiny = enc_fwd_tiny(d, *c);
     const bool persist = tiny || chain_persist(d, c->B);
     const bool merged = !persist && fused && dirs == 2 && !d.bn && chain_merge_dirs();
     SideGuard side_guard(s);
@@ -570,6 +607,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = dirs;
         a.sync = reinterpret_cast<unsigned*>(w.sync);
         a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+        a.zero_next = a.sync + TINY_CHAIN_SYNC_WORDS;
         DVAE_TRY(tiny_chain_fwd(a, s));
     } else if (persist) {
         EncChainArgs a = {};
@@ -798,8 +836,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             e.tidx = k == 0 ? bv.succ_idx : bv.pred_idx;
         }
         a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = dirs;
-        a.sync = reinterpret_cast<unsigned*>(w.sync);
+        a.sync = reinterpret_cast<unsigned*>(w.sync) + TINY_CHAIN_SYNC_WORDS;  // slot 1
         a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+        a.sync_is_zero = enc_fwd_tiny(d, *c) ? 1 : 0;  // dvae_encode_forward's persistent launch zeroed it
         a.poison = pg + L.whh[0];  // a timed-out wait turns the gradients NaN (the weight-gradient products below add to it)
         DVAE_TRY(tiny_chain_bwd(a, s));
         if (dirs == 2) DVAE_TRY(fork_side(side_guard));  // the two directions' weight gradients on two streams
@@ -873,14 +912,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     const float* gi = pw + L.gi[2];
     const float* bhn = pw + L.bhn[2];
 
-    // level-major batches (every graph full size: all of the reference's data sets) run the
-    // per-level predictor products beside the chain
-    static const int by_level_knob = [] { const char* v = getenv("DVAE_BY_LEVEL"); return v ? atoi(v) : 1; }();
-    // (small batches: the per-level side-stream launches cost more host time -- a fork and three launches per level --
-    // than their overlap gains, and batch 32 is bound by the host's enqueue rate; measured on the step, by level vs whole
-    // batch: B = 32 26.2 k vs 29.9 k DAGs/s, 128 93.3 k vs 98.2 k, 256 149.6 k vs 152.2 k, 512 200.4 k vs 197.3 k;
-    // DVAE_BY_LEVEL=2 forces the per-level form at every size)
-    const bool by_level = !d.bn && c->level_major != 0 && (by_level_knob == 2 || (by_level_knob == 1 && c->B > 256));
+    const bool by_level = loss_by_level(d, *c);
     SideGuard side_guard(s);
     Side*& side = side_guard.sd;
     if (by_level) DVAE_TRY(side_acquire(side_guard));
@@ -899,7 +931,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
     const bool fused = chain_fused(d, c->B);
-    const bool tiny = fused && !by_level && chain_tiny_persist(d, c->B);  // the decoder's chain as one persistent launch
+    const bool tiny = loss_fwd_tiny(d, *c);  // the decoder's chain as one persistent launch
     if (tiny) {
         TinyChainArgs a = {};
         tiny_dir_fwd(a.d[0], w.agg, w.gates, w.ghn, w.st, w.gm, w.msg, whh, pw + L.wgm[0], gi, bhn, pw + L.gv[0],
@@ -908,6 +940,7 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
         a.sync = reinterpret_cast<unsigned*>(w.sync);
         a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
         a.poison = w.sums;  // a timed-out wait turns the loss NaN (the pair kernel adds its sum to it)
+        a.zero_next = a.sync + TINY_CHAIN_SYNC_WORDS;
         DVAE_TRY(tiny_chain_fwd(a, s));
     } else if (fused) {
         DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
@@ -1101,8 +1134,9 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             e.toff = bv.succ_off; e.tidx = bv.succ_idx;
             e.gsrc2 = w.dagg + p0 * Hp; e.off2 = bv.pt_off; e.idx2 = bv.pt_idx;
             a.types = bv.types; a.B = B; a.Hp = Hp; a.n = n; a.ndirs = 1;
-            a.sync = reinterpret_cast<unsigned*>(w.sync);
+            a.sync = reinterpret_cast<unsigned*>(w.sync) + TINY_CHAIN_SYNC_WORDS;  // slot 1
             a.status = a.sync + TINY_CHAIN_SYNC_WORDS - 64;
+            a.sync_is_zero = loss_fwd_tiny(d, *c) ? 1 : 0;  // dvae_loss_forward's persistent launch zeroed it
             a.poison = pg + L.whh[2];  // a timed-out wait turns the gradients NaN (the weight-gradient products add to it)
             DVAE_TRY(tiny_chain_bwd(a, s));
         }

@@ -36,7 +36,7 @@ def _batches(n_items, batch_size):
     return [(lo, min(lo + batch_size, n_items)) for lo in range(0, n_items, batch_size)]
 
 
-def _packed_batches(model, ga, order, batch_size, prefetch):
+def _packed_batches(model, ga, order, batch_size, prefetch, caps=None):
     """Yields (indices, packed DAGBatch).  With prefetch the next batches are packed (C++ packer,
     which releases the GIL, + the H2D copy of the index blob) by a background thread while the GPU
     works on the current one."""
@@ -44,7 +44,7 @@ def _packed_batches(model, ga, order, batch_size, prefetch):
     if not prefetch or len(spans) < 2:
         for lo, hi in spans:
             idx = order[lo:hi]
-            yield idx, model._collate_fn(ga.select(idx))
+            yield idx, model._collate_fn(ga.select(idx), caps)
         return
     import queue
     import threading
@@ -68,7 +68,7 @@ def _packed_batches(model, ga, order, batch_size, prefetch):
                 torch.cuda.set_device(dev)
             for lo, hi in spans:
                 idx = order[lo:hi]
-                if not put((idx, model._collate_fn(ga.select(idx)))):
+                if not put((idx, model._collate_fn(ga.select(idx), caps))):
                     return
             put(None)
         except BaseException as e:  # surfaces in the consumer
@@ -96,8 +96,123 @@ def _packed_batches(model, ga, order, batch_size, prefetch):
         t.join()
 
 
+class _StaticBatch(object):
+    """What encode() / loss() need of a batch, with the index blob in a FIXED device buffer (the captured step reads it)"""
+    is_dag_batch = True
+
+    def __init__(self, like, blob):
+        self.B, self.max_n, self.nvt, self.is_bn = like.B, like.max_n, like.nvt, like.is_bn
+        self.counts = like.counts
+        self.blob = blob
+        self.device = like.device
+        self.arrays = None
+
+    def wait_ready(self):
+        pass
+
+    def __len__(self):
+        return self.B
+
+
+class GraphedTrainStep(object):
+    """One train step (train.py:224-253: zero_grad -> encode -> loss -> backward -> Adam) captured ONCE as a HIP graph
+    and replayed for every later batch: the host then pays two small copies and one graph launch per step instead of
+    ~120 Python / launch calls (profiles/r03_host_cost_cfg1.txt), which is what bounds the reference's own recipe
+    (batch 32) once the GPU side is fast.
+
+    Needs a launch sequence that does not depend on the batch: batches packed shape-stable (batching.padding_caps ->
+    model._collate_fn(G, caps=...)), an optimizer whose per-step scalars live on the device
+    (optim.FlatAdam(capturable=True)) and the gradient sink (no autograd accumulation kernels).  The first `warmup`
+    eligible batches run eagerly on the capture stream (they are ordinary train steps; the library creates its side
+    streams there), the next one is captured, and from then on every eligible batch is a replay.  A batch that is not
+    eligible -- other counts (the epoch's last, smaller batch; a batch above the caps), `eps` given to a step captured
+    without it or the reverse -- runs the eager step, with the same result.
+
+    Single process only: the gradient all-reduce is not captured (N > 1 ranks keep the eager step)."""
+
+    def __init__(self, model, optimizer, beta=0.005, warmup=2):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs optim.FlatAdam(..., capturable=True)")
+        if optimizer.extra is not None:
+            raise ValueError("GraphedTrainStep: extra parameters (predictor head) are stepped by torch's Adam; not captured")
+        self.model, self.opt, self.beta = model, optimizer, beta
+        self.warmup = int(warmup)
+        self.n_warm = 0
+        self.graph = None
+        self.key = None
+        self.stream = torch.cuda.Stream(device=model.get_device())
+        self.replays = 0
+        self.eager_steps = 0
+
+    @staticmethod
+    def _key(batch, eps):
+        c = batch.counts
+        return tuple(getattr(c, f) for f, _ in c._fields_) + (eps is not None,)
+
+    def _eager(self, batch, eps):
+        self.opt.zero_grad()
+        mu, logvar = self.model.encode(batch)
+        loss, recon, kld = self.model.loss(mu, logvar, batch, beta=self.beta, eps=eps)
+        loss.backward()
+        self.opt.step()
+        self.eager_steps += 1
+        return loss.detach(), recon.detach(), kld.detach()
+
+    def _capture(self, batch, eps):
+        dev = self.model.get_device()
+        self.static_blob = torch.empty_like(batch.blob)
+        self.static_eps = torch.empty(batch.B, self.model.nz, dtype=torch.float32, device=dev) if eps is not None else None
+        self.static_batch = _StaticBatch(batch, self.static_blob)
+        self.opt.sync_device_state()  # nothing inside the capture may have to touch lr / steps on the device
+        self.graph = torch.cuda.CUDAGraph()
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.opt.zero_grad()
+            mu, logvar = self.model.encode(self.static_batch)
+            loss, recon, kld = self.model.loss(mu, logvar, self.static_batch, beta=self.beta, eps=self.static_eps)
+            loss.backward()
+            self.opt.step()
+            self.out = (loss.detach(), recon.detach(), kld.detach())
+        # (capturing executed nothing: Adam's host-side step count moved, the device's has not; the replay that
+        # follows IS that step)
+        self.key = self._key(batch, eps)
+
+    def __call__(self, batch, eps=None):
+        """-> (loss, recon, kld) of the step, 0-dim device tensors (replays: the same three static tensors every time:
+        read or accumulate them before the next call)"""
+        ok = (getattr(batch, "padded", False) and self.model.training and self.model._grad_sink and
+              not self.opt.reducer._collective())
+        if not ok or (self.key is not None and self._key(batch, eps) != self.key):
+            return self._eager(batch, eps)
+        if self.graph is None:
+            if self.n_warm < self.warmup:
+                self.n_warm += 1
+                cur = torch.cuda.current_stream(self.model.get_device())
+                self.stream.wait_stream(cur)
+                with torch.cuda.stream(self.stream):
+                    out = self._eager(batch, eps)
+                cur.wait_stream(self.stream)
+                return out
+            self._capture(batch, eps)
+            first = True
+        else:
+            first = False
+        batch.wait_ready()
+        self.static_blob.copy_(batch.blob, non_blocking=True)
+        if eps is not None:
+            self.static_eps.copy_(eps, non_blocking=True)
+        if not first:
+            self.opt.sync_device_state()  # a scheduler may have changed lr
+        self.graph.replay()
+        if not first:
+            self.opt.replayed()
+        self.replays += 1
+        return self.out
+
+
 def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predictor=False, reducer=None,
-                on_batch=None, prefetch=False):
+                on_batch=None, prefetch=False, graphed=None, caps=None):
     """One pass over the training set (train.py:209-262).  Returns the SUMS over the epoch of
     (loss, recon, kld[, pred]) exactly as the reference accumulates them.  `rng` shuffles the
     data (the reference shuffles its list in place with the global `random`); `reducer`
@@ -105,7 +220,10 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
     whole-job sums back.  `prefetch=True` packs the next batches in a background thread; off by
     default: the C++ packer takes ~20 us for 32 graphs, ~0.3 ms for 1024, the host runs ahead of the
     GPU anyway, and the second thread costs the enqueueing one more than it saves (epoch at batch
-    32: 29.0 k DAGs/s without, 25.9 k with; at batch 1024: 238 k / 235 k)."""
+    32: 29.0 k DAGs/s without, 25.9 k with; at batch 1024: 238 k / 235 k).
+    `graphed` (a GraphedTrainStep for this model and optimizer) + `caps` (batching.padding_caps of the data set):
+    the batches are packed shape-stable and the step is replayed from one captured HIP graph; batches that do not
+    fit (the last, smaller one) run the eager step inside it."""
     model.train()
     ga, ys = _as_arrays(train_data, model.max_n)
     order = list(range(len(ga)))
@@ -113,7 +231,16 @@ def train_epoch(model, optimizer, train_data, batch_size=32, rng=random, predict
     dev = model.get_device()
     tot = torch.zeros(4, dtype=torch.float64, device=dev)
     done = 0
-    for idx, batch in _packed_batches(model, ga, order, batch_size, prefetch):
+    if graphed is not None and (predictor or reducer is not None):
+        raise ValueError("train_epoch: the captured step covers neither the predictor head nor the all-reduce")
+    for idx, batch in _packed_batches(model, ga, order, batch_size, prefetch, caps):
+        if graphed is not None:
+            l3 = graphed(batch)
+            tot[:3] += torch.stack(l3).double()
+            done += len(idx)
+            if on_batch is not None:
+                on_batch(done, len(order))
+            continue
         optimizer.zero_grad()
         mu, logvar = model.encode(batch)
         loss, recon, kld = model.loss(mu, logvar, batch)

@@ -325,13 +325,13 @@ class DVAE(nn.Module):
         self._reducer = reducer if on else None  # told when the decoder's gradients are final
         return self
 
-    def _as_batch(self, G):
-        if isinstance(G, DAGBatch):
+    def _as_batch(self, G, caps=None):
+        if isinstance(G, DAGBatch) or getattr(G, "is_dag_batch", False):
             return G
         if not isinstance(G, (list, tuple, GraphArrays)):
             G = [G]  # single graph, as models.py:722-723
         arrays = graphs_to_arrays(G, self.max_n)
-        return DAGBatch(arrays, self.nvt, self.START_TYPE, self._is_bn, self.get_device())
+        return DAGBatch(arrays, self.nvt, self.START_TYPE, self._is_bn, self.get_device(), caps=caps)
 
     def set_mfma_dtype(self, mfma_dtype):
         """'fp32' (default: every contraction exact fp32, the parity mode) or 'bf16' (matrix-unit
@@ -355,9 +355,10 @@ class DVAE(nn.Module):
         self._named_cache = None
         return super(DVAE, self)._apply(fn, *a, **kw)
 
-    def _collate_fn(self, G):
-        """Packs the batch once; encode() and loss() both accept the result."""
-        return self._as_batch(G)
+    def _collate_fn(self, G, caps=None):
+        """Packs the batch once; encode() and loss() both accept the result.  `caps` (batching.padding_caps): pack
+        shape-stable, for harness.GraphedTrainStep."""
+        return self._as_batch(G, caps)
 
     def encode(self, G):
         batch = self._as_batch(G)

@@ -16,9 +16,12 @@ from .dist import GradSumReducer
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, extra_params=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, reducer=None, extra_params=None, capturable=False):
         """extra_params: parameters outside the hot path (e.g. the optional `model.predictor` head of
-        train.py:165-172); they are stepped by a torch.optim.Adam with the same hyper-parameters."""
+        train.py:165-172); they are stepped by a torch.optim.Adam with the same hyper-parameters.
+        capturable: the learning rate and the step count live in device memory (dvae_adam_step_dev_f32; the
+        counterpart of torch.optim.Adam(capturable=True)), so that a captured train step can be replayed
+        (harness.GraphedTrainStep); same arithmetic."""
         self.model = model
         extra = [p for p in (extra_params or [])]
         self.extra = torch.optim.Adam(extra, lr=lr, betas=betas, eps=eps) if extra else None
@@ -37,6 +40,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(r.flat)
         self.exp_avg_sq = torch.zeros_like(r.flat)
         self.steps = 0
+        self.capturable = bool(capturable)
+        self._lr_dev = self._step_dev = None   # device copies of lr / steps (capturable)
+        self._dev_mirror = (None, None)        # the (lr, steps) the device copies are known to hold
         model._pw = None  # parameter storage moved: pack afresh
 
     def zero_grad(self, set_to_none=False):
@@ -56,15 +62,25 @@ class FlatAdam(torch.optim.Optimizer):
                 raise _lib.DvaeHipError("FlatAdam: a parameter (or its .grad) no longer lives in the flat buffers "
                                         "(was the model moved or its gradients set to None after the optimizer "
                                         "was built?); build the optimizer after the last .to()")
-        self.steps += 1
         lib = _lib.load()
         # zero_grad: with the gradient sink attached every write to the flat gradient buffer goes through the model
         # (which clears `reducer.clean`), so the kernel can leave the buffer zeroed and the next zero_grad() is free
         zero = int(bool(getattr(self.model, "_grad_sink", False)) and getattr(self.model, "_reducer", None) is r)
-        _lib.check(lib.dvae_adam_step_f32(self.flat_p.data_ptr(), self.reducer.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                          self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]),
-                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, zero,
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dvae_adam_step_f32")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.capturable:
+            self.sync_device_state()
+            _lib.check(lib.dvae_adam_step_dev_f32(self.flat_p.data_ptr(), r.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                                  self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self._lr_dev.data_ptr(),
+                                                  float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                  self._step_dev.data_ptr(), zero, stream), "dvae_adam_step_dev_f32")
+            self.steps += 1
+            self._dev_mirror = (self._dev_mirror[0], self.steps)  # the kernel pair advanced the device count
+        else:
+            self.steps += 1
+            _lib.check(lib.dvae_adam_step_f32(self.flat_p.data_ptr(), r.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]),
+                                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, zero,
+                                              stream), "dvae_adam_step_f32")
         # (set either way: with the sink detached autograd's own accumulation writes into the .grad views behind the
         # reducer's back, so the buffer is only known to be zero when THIS step's kernel zeroed it)
         r.clean = bool(zero)
@@ -75,6 +91,26 @@ class FlatAdam(torch.optim.Optimizer):
                 eg["lr"] = g["lr"]  # follows a scheduler attached to this optimizer
             self.extra.step()
         return loss
+
+    def sync_device_state(self):
+        """capturable: brings the device copies of (lr, steps) up to the host's values where they differ (a scheduler
+        changed lr, a checkpoint was loaded).  Two tiny fills at most; nothing when they agree."""
+        dev = self.flat_p.device
+        if self._lr_dev is None:
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._dev_mirror = (None, None)
+        lr = float(self.param_groups[0]["lr"])
+        if self._dev_mirror[0] != lr:
+            self._lr_dev.fill_(lr)
+        if self._dev_mirror[1] != self.steps:
+            self._step_dev.fill_(self.steps)
+        self._dev_mirror = (lr, self.steps)
+
+    def replayed(self):
+        """a captured step() was replayed: the device count advanced by one, the host's follows"""
+        self.steps += 1
+        self._dev_mirror = (self._dev_mirror[0], self.steps)
 
     # ------------------------------------------------------------------ checkpoints
     # The layout written and read is torch.optim.Adam's own (what the reference saves as

@@ -171,3 +171,75 @@ def test_batches_outlive_the_kernels_that_read_them():
 
     kept, dropped = run(True), run(False)
     assert np.isfinite(kept) and abs(kept - dropped) <= 1e-6 * abs(kept), (kept, dropped)
+
+
+def _twin_models(hs, bidir):
+    def make():
+        torch.manual_seed(11)
+        return dvae_amd.DVAE(8, 8, 0, 1, hs=hs, nz=16, bidirectional=bidir).cuda()
+    return make(), make()
+
+
+@pytest.mark.parametrize("hs,bidir", [(64, True), (501, False)], ids=["hs64-bidir", "hs501-cfg1"])
+def test_graphed_step_equals_eager_step(hs, bidir):
+    """harness.GraphedTrainStep: the train step captured once as a HIP graph and replayed over shape-stable (padded)
+    batches gives what the eager step gives -- loss of every step and the parameters after the last one -- including
+    a batch that does not fit (smaller: runs eagerly inside it) and a learning-rate change between replays (the
+    capturable optimizer keeps lr and the step count on the device)."""
+    B, steps = 32, 9
+    ga, _ = _dataset(B * steps, 3)
+    caps = dvae_amd.batching.padding_caps(ga, B, 8)
+    assert caps is not None
+    gen = torch.Generator().manual_seed(5)
+    eps = [torch.randn(B, 16, generator=gen).cuda() for _ in range(steps)]
+    m_e, m_g = _twin_models(hs, bidir)
+    o_e = dvae_amd.optim.FlatAdam(m_e, lr=1e-3)
+    o_g = dvae_amd.optim.FlatAdam(m_g, lr=1e-3, capturable=True)
+    graphed = H.GraphedTrainStep(m_g, o_g, warmup=2)
+    m_e.train(); m_g.train()
+    n_padded = 0
+    for i in range(steps):
+        sel = np.arange(i * B, (i + 1) * B)
+        if i == 5:
+            sel = sel[:20]  # a smaller batch in the middle: not eligible, runs the eager step
+        if i == 6:
+            for o in (o_e, o_g):
+                o.param_groups[0]["lr"] = 2.5e-4  # what ReduceLROnPlateau does
+        e = eps[i][:len(sel)]
+        b_e = m_e._collate_fn(ga.select(sel))
+        o_e.zero_grad()
+        mu, lv = m_e.encode(b_e)
+        l_e, _, _ = m_e.loss(mu, lv, b_e, eps=e)
+        l_e.backward()
+        o_e.step()
+        b_g = m_g._collate_fn(ga.select(sel), caps)
+        n_padded += int(b_g.padded)
+        l_g = graphed(b_g, eps=e)[0]
+        assert abs(l_g.item() - l_e.item()) <= 2e-5 * abs(l_e.item()), (i, l_g.item(), l_e.item())
+    assert n_padded >= steps - 2 and graphed.replays >= steps - 4 and graphed.eager_steps >= 3
+    assert o_g.steps == o_e.steps == steps
+    pe = dict(m_e.named_parameters())
+    for k, p in m_g.named_parameters():
+        d = (p - pe[k]).norm() / (pe[k].norm() + 1e-30)
+        assert d < 2e-5, (k, d.item())
+    # device-side optimizer state followed: one more eager step on both agrees as well
+    assert int(o_g._step_dev.item()) == steps
+
+
+def test_train_epoch_with_a_graphed_step_trains():
+    """train_epoch(graphed=..., caps=...): an epoch loop that replays the captured step (in-graph normal draw for
+    reparameterize) reduces the loss like the eager loop does."""
+    torch.manual_seed(0)
+    train = _dataset(200, 0)  # 6 full batches + a remainder of 8
+    model = dvae_amd.DVAE(8, 8, 0, 1, hs=64, nz=16, bidirectional=True).cuda()
+    opt = dvae_amd.optim.FlatAdam(model, lr=2e-3, capturable=True)
+    caps = dvae_amd.batching.padding_caps(train[0], 32, 8)
+    graphed = H.GraphedTrainStep(model, opt)
+    rng = random.Random(0)
+    losses = []
+    for epoch in range(6):
+        tl, rl, kl = H.train_epoch(model, opt, train, batch_size=32, rng=rng, graphed=graphed, caps=caps)
+        assert np.isfinite(tl) and abs(tl - (rl + 0.005 * kl)) <= 1e-3 * abs(tl)
+        losses.append(tl / 200)
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert graphed.replays >= 6 * 6 - 3 - 6 and graphed.eager_steps >= 6

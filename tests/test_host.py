@@ -72,6 +72,54 @@ def test_packer_counts_and_dedup():
         assert sorted(t[key + "_pairs"].tolist()) == list(range(c.NP))
 
 
+def test_padded_export_is_shape_stable_and_inert():
+    """dvae_batch_export_padded (include/dvae_hip.h): batches of the same (B, max_n) packed under the same caps have
+    IDENTICAL counts (hence blob layout, workspace sizes and launch sequence: what replaying one captured train step
+    needs), and the padding entries change nothing: the loss evaluated through the padded tables is the reference's."""
+    d, cls, ctor = load_case(golden_files("dvae_tiny_bi_full")[0])
+    cfg = cfg_of(cls, ctor)
+    sd = state_dict_of(d, torch.float64)
+    ga = dvae_amd.GraphArrays.from_dense(d["types"], d["adj"], d["n_g"])
+    caps = dvae_amd.batching.padding_caps(ga, len(ga), ctor["nvt"])
+    assert caps is not None
+    plain = dvae_amd.DAGBatch(ga, ctor["nvt"], 0, False, "cpu")
+    padded = dvae_amd.DAGBatch(ga, ctor["nvt"], 0, False, "cpu", caps=caps)
+    assert padded.padded and not plain.padded
+    c, q = plain.counts, padded.counts
+    assert (q.E, q.PT, q.PL, q.NB, q.CH) == (caps.E, caps.PT, caps.PL, caps.NB, caps.CH)
+    assert q.PT >= c.PT and q.NB >= c.NB and q.CH >= c.CH + (q.NB - c.NB)
+    for f in ("B", "n", "T", "nB", "NA", "NP", "CA", "CC", "R", "RL", "NCE", "HGF", "HGB", "level_major"):
+        assert getattr(c, f) == getattr(q, f), f
+    mu, lv, (L, R, K) = BI.forward(cfg, sd, padded, torch.from_numpy(d["eps"]).double())
+    assert abs(L.item() - d["loss3"][0]) < 1e-6 * d["loss3"][0]
+    t = BI.unpack_blob(padded)
+    # padding rows of the EB table: gathered from the first type row, referenced by no pair; the zero row is NB_cap
+    assert (t["rowsB"][c.NB:] == c.nB).all() and t["pair_h"].max() < c.NB
+    # every padding row has an empty backward chunk of its own (its gradient row is written whole: zeros)
+    rows_of_empty = set(int(r) & 0x7fffffff for r, a, b in zip(t["ch_row"], t["ch_off"][:-1], t["ch_off"][1:]) if a == b)
+    assert set(range(c.NB, q.NB)) <= rows_of_empty
+    assert sorted(t["ch_pairs"].tolist()) == list(range(c.NP))
+    # another batch of the same shape, other edges: the same counts, field for field
+    rng = np.random.default_rng(0)
+    adj2 = np.triu((rng.random(d["adj"].shape) < 0.35), 1).astype(np.uint8)
+    for v in range(1, adj2.shape[1]):
+        adj2[:, v - 1, v] = 1
+    other = dvae_amd.DAGBatch(dvae_amd.GraphArrays.from_dense(d["types"], adj2, d["n_g"]), ctor["nvt"], 0, False, "cpu", caps=caps)
+    if other.padded:
+        for f, _ in q._fields_:
+            assert getattr(other.counts, f) == getattr(q, f), f
+        assert other.blob_host.numel() == padded.blob_host.numel()
+    # a batch above a cap falls back to the plain export
+    tight = dvae_amd._lib.BatchCaps()
+    tight.E, tight.PT, tight.PL, tight.NB, tight.CH = caps.E, c.PT - 1, caps.PL, caps.NB, caps.CH
+    assert not dvae_amd.DAGBatch(ga, ctor["nvt"], 0, False, "cpu", caps=tight).padded
+    # graphs of different sizes do not qualify
+    d2, cls2, ctor2 = load_case(golden_files("dvae_tiny_bi_var")[0])
+    ga2 = dvae_amd.GraphArrays.from_dense(d2["types"], d2["adj"], d2["n_g"])
+    assert dvae_amd.batching.padding_caps(ga2, len(ga2), ctor2["nvt"]) is None
+    assert not dvae_amd.DAGBatch(ga2, ctor2["nvt"], 0, False, "cpu", caps=caps).padded
+
+
 def test_packer_level_major_flag():
     """full-size batches (the reference's data sets) are flagged level-major: EA row i and vertex-type row i are
     slot i, which lets the loss forward run those products level by level; ragged or BN batches are not"""
@@ -167,7 +215,7 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     import subprocess
     L = dvae_amd._lib
     structs = {"dvae_model_desc": L.ModelDesc, "dvae_batch_counts": L.BatchCounts, "dvae_gemm_desc": L.GemmDesc,
-               "dvae_level_desc": L.LevelDesc}
+               "dvae_level_desc": L.LevelDesc, "dvae_batch_caps": L.BatchCaps}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "dvae_hip.h"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
