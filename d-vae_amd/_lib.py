@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libdvae_hip.so")
+# DVAE_EXP_LIB=<path>: load an alternative build of the library (A/B and ablation runs, tools/*_ablate.sh); diagnostics only
+LIB_PATH = os.path.abspath(os.environ["DVAE_EXP_LIB"]) if os.environ.get("DVAE_EXP_LIB") else os.path.join(HERE, "csrc", "libdvae_hip.so")
 NUM_PARAMS = 36
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     "dvae_version": (_I, []),
     "dvae_gemm_f32": (_I, [C.POINTER(GemmDesc), _P]),
     "dvae_gemm_bf16": (_I, [C.POINTER(GemmDesc), _P]),
+    "dvae_gemm_skinny_f32": (_I, [C.POINTER(GemmDesc), _I, _P]),
+    "dvae_debug_set_gemm_skinny_mmac": (_I, [_I]),
     "dvae_f32_to_bf16": (_I, [_P, _P, C.c_int64, _P]),
     "dvae_debug_set_kmajor_span_limit": (_I, [C.c_int64]),
     "dvae_gather_sum_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),

@@ -458,6 +458,11 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
         }
     }
 
+    if (knob_tile == 0 && knob_split == 0) {  // products of few rows: 16-row tiles, the waves as K slices (gemm_skinny.hip)
+        const int rc = gemm_skinny(d, s, 0);
+        if (rc != 1) return rc;
+    }
+
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C;
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;

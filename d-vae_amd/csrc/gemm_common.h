@@ -137,6 +137,7 @@ inline bool gemm_vec_epilogue_ok(const GemmParams& p) {
            (p.bias == nullptr || ((uintptr_t)p.bias % 16) == 0) && ((uintptr_t)p.relu_mask % 16) == 0;
 }
 
+int gemm_skinny(const dvae_gemm_desc& d, hipStream_t s, int force_nt);  // gemm_skinny.hip: 1 = not served there
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16.hip
 int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s);  // gemm_bf16_nn.hip: 1 = not served there
 int gemm_check(const dvae_gemm_desc& d, int kmult);     // gemm.hip: argument checks common to both

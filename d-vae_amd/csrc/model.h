@@ -111,6 +111,7 @@ static inline PackedLayout make_layout(const Dims& d) {
 // internal kernels shared between translation units
 int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split = 0);  // max_split > 0 caps the split-K factor
 int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);
+int gemm_skinny(const dvae_gemm_desc& d, hipStream_t s, int force_nt);  // gemm_skinny.hip: products of few rows; 1 = not served there
 int scale_inplace(float* x, const float* s, int n, hipStream_t st);
 int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
                     float* ghn_out, int rows, int Hp, hipStream_t s);

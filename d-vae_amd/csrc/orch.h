@@ -70,6 +70,10 @@ static inline void use_bf16_weight_copy(dvae_gemm_desc& g) {
 }
 static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s, int max_split = 0) {
     if (!tl_bf16) return gemm(g, s, max_split);
+    {  // products of few rows run in exact fp32 in either mode (gemm_skinny.hip), as the levels of at most 256 rows do
+        const int rc = gemm_skinny(g, s, 0);
+        if (rc != 1) return rc;
+    }
     dvae_gemm_desc h = g;
     use_bf16_weight_copy(h);
     return gemm_bf16(h, s);

@@ -68,6 +68,18 @@ typedef struct dvae_gemm_desc {
                                gemm_bf16_nn.hip.  dvae_gemm_f32 refuses them. */
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
+/* The same product on the kernel for FEW ROWS (csrc/gemm_skinny.hip): 16-row x (16 nt)-column tiles whose eight waves
+ * are K slices, operands straight from L2 into 16x16x4 MFMA fragments.  dvae_gemm_f32 (and, in bf16 mode, the train
+ * step: such products stay exact fp32) picks it by itself up to 1.6e8 multiply-adds (DVAE_GEMM_SKINNY_MMAC); this entry point forces
+ * it at any M with nt = 1, 2 or 4 blocks per tile (0: the library's choice; a K-major B takes 1 or 4) - tests and
+ * tools/gemm_skinny_bench.py.  Serves A K-contiguous (a_rows allowed), no b_rows, K % 16 == 0, N % 4 == 0, 16-byte
+ * aligned operands; anything else is refused.  The products it replaces: every nn.Linear forward / input gradient of
+ * a batch-32 step, e.g. models.py:563-567 (add_vertex), :568-572 (add_edge), :557-558 (fc1, fc2), :562 (fc3). */
+int dvae_gemm_skinny_f32(const dvae_gemm_desc* d, int32_t nt, void* stream);
+/* Diagnostics: the size (millions of multiply-adds) up to which products go to that kernel by themselves; 0 = never,
+ * negative restores the default (160, or DVAE_GEMM_SKINNY_MMAC).  Tests of the bf16 mode set 0 so that small test
+ * batches reach the bf16 kernels.  Process-wide, not thread-safe; no counterpart in the reference. */
+int dvae_debug_set_gemm_skinny_mmac(int32_t mmac);
 /* Diagnostics: lowers the span (bytes from its base pointer) a K-major operand may cover, normally
  * 4 GiB - a contraction over a longer K-major operand runs as accumulating K chunks, a longer gathered one is
  * refused - so that tests reach both paths at small sizes.  0 restores the default.  Process-wide, not

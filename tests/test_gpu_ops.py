@@ -88,6 +88,102 @@ def test_gemm_dgrad_kmajor_b():
     assert (out - ref).abs().max() < 1e-3
 
 
+def _gemm_skinny(A, B, Cm, M, N, K, nt, bkm=0, a_rows=None, c_rows=None, bias=None, act=0, acc=0, mask=None):
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
+    d.a_rows = a_rows.data_ptr() if a_rows is not None else None
+    d.c_rows = c_rows.data_ptr() if c_rows is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.relu_mask = mask.data_ptr() if mask is not None else None
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), Cm.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.b_kmajor, d.act, d.accumulate = bkm, act, acc
+    L.check(L.load().dvae_gemm_skinny_f32(C.byref(d), nt, _s()), "gemm_skinny")
+    torch.cuda.synchronize()
+
+
+# the shapes of a batch-32 step (tools/gemm_skinny_bench.py) plus ragged ones: M not a multiple of 16, N a multiple of
+# 4 only (partial blocks and tiles), K = 16 (one step: seven of the eight K slices idle), one row
+_SKINNY = [(32, 128, 512), (224, 32, 1024), (298, 2048, 512), (157, 1536, 512), (32, 512, 64), (1, 16, 16), (37, 52, 48),
+           (333, 100, 96), (16, 4, 16)]
+
+
+@pytest.mark.parametrize("M,N,K", _SKINNY)
+@pytest.mark.parametrize("bkm", [0, 1])
+@pytest.mark.parametrize("nt", [0, 1, 2, 4])
+def test_gemm_skinny_matches_fp64(M, N, K, bkm, nt):
+    """csrc/gemm_skinny.hip against a float64 product: tolerance = fp32 rounding of a K-term sum, 16 eps sqrt(K) |a||b|"""
+    if bkm and nt == 2:
+        pytest.skip("a K-major B takes one block or four interleaved blocks per tile")
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K + bkm)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn((K, N) if bkm else (N, K), device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm_skinny(A, B, out, M, N, K, nt, bkm=bkm)
+    ref = _ref(A, B if bkm else B.t())
+    assert (out - ref).abs().max() <= 2e-6 * K ** 0.5 * 16
+    # the same order of additions whatever the tile width: bit-identical across nt
+    if nt in (1, 4):
+        out2 = torch.full((M, N), float("nan"), device="cuda")
+        _gemm_skinny(A, B, out2, M, N, K, 4 if nt == 1 else 1, bkm=bkm)
+        assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("bkm", [0, 1])
+@pytest.mark.parametrize("nt", [1, 4])
+def test_gemm_skinny_epilogue_gather_scatter_mask(bkm, nt):
+    g = torch.Generator(device="cuda").manual_seed(11 + bkm)
+    rows_total, M, N, K = 500, 260, 160, 96
+    X = torch.randn(rows_total, K, device="cuda", generator=g)
+    W = torch.randn((K, N) if bkm else (N, K), device="cuda", generator=g)
+    Wt = W if bkm else W.t()
+    bias = torch.randn(N, device="cuda", generator=g)
+    a_rows = torch.randperm(rows_total, device="cuda", generator=g)[:M].int()
+    c_rows = torch.randperm(400, device="cuda", generator=g)[:M].int()
+    for act in (0, 1, 2):
+        out = torch.ones(400, N, device="cuda")
+        _gemm_skinny(X, W, out, M, N, K, nt, bkm=bkm, a_rows=a_rows, c_rows=c_rows, bias=bias, act=act, acc=1)
+        y = _ref(X[a_rows.long()], Wt) + bias
+        y = [y, torch.relu(y), torch.tanh(y)][act]
+        ref = torch.ones(400, N, device="cuda")
+        ref[c_rows.long()] += y
+        assert (out - ref).abs().max() < 2e-4
+    # ReLU-backward mask laid out like C (rows named by c_rows), no accumulate
+    mask = torch.randn(400, N, device="cuda", generator=g)
+    out = torch.full((400, N), 7.0, device="cuda")
+    _gemm_skinny(X, W, out, M, N, K, nt, bkm=bkm, a_rows=a_rows, c_rows=c_rows, mask=mask)
+    ref = torch.full((400, N), 7.0, device="cuda")
+    ref[c_rows.long()] = torch.where(mask[c_rows.long()] > 0, _ref(X[a_rows.long()], Wt), torch.zeros((), device="cuda"))
+    assert (out - ref).abs().max() < 2e-4
+
+
+def test_gemm_skinny_layout_identity_and_refusals():
+    K = 64
+    A = torch.eye(K, device="cuda")
+    W = torch.arange(96 * K, device="cuda", dtype=torch.float32).reshape(96, K)
+    for nt in (1, 2, 4):
+        out = torch.zeros(K, 96, device="cuda")
+        _gemm_skinny(A, W, out, K, 96, K, nt)
+        assert torch.equal(out, W.t().contiguous())
+    Wk = W.t().contiguous()  # [K][96]: K-major
+    for nt in (1, 4):
+        out = torch.zeros(K, 96, device="cuda")
+        _gemm_skinny(A, Wk, out, K, 96, K, nt, bkm=1)
+        assert torch.equal(out, Wk)
+    # dvae_gemm_f32 picks this kernel for few rows and gives the same bits as the forced call
+    out1, out2 = torch.zeros(K, 96, device="cuda"), torch.zeros(K, 96, device="cuda")
+    X = torch.randn(K, K, device="cuda")
+    _gemm(X, W, out1, K, 96, K)
+    _gemm_skinny(X, W, out2, K, 96, K, 0)
+    assert torch.equal(out1, out2)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+    d.lda, d.ldb, d.ldc, d.M, d.N, d.K = K, K, 96, K, 96, K
+    assert L.load().dvae_gemm_skinny_f32(C.byref(d), 3, _s()) != 0  # nt must be 0, 1, 2 or 4
+    d.a_kmajor = 1
+    assert L.load().dvae_gemm_skinny_f32(C.byref(d), 1, _s()) != 0  # a K-major A is not served
+
+
 @pytest.mark.parametrize("rows,N,K", [(8192, 1536, 512), (333, 64, 32), (5000, 32, 1536), (70, 128, 512)])
 def test_gemm_wgrad_splitk(rows, N, K):
     g = torch.Generator(device="cuda").manual_seed(rows)
