@@ -15,12 +15,21 @@ __device__ __forceinline__ float4 ld4c(const float* p) { return *reinterpret_cas
 // The loss terms are summed into sums[0..2] = {pair BCE, vertex CE, KLD} by kernels that may run on two streams; each
 // of their workgroups, after its own atomic add, draws a ticket from sums[4], and the one that draws the last of
 // `total` tickets writes out3 = {res + beta kld, res, kld} (models.py:858-860): no separate finalize launch, and no
-// order between the kernels.  Called by ONE thread per workgroup; sums are read back with atomics (memory side).
-__device__ __forceinline__ void loss_ticket(float* sums, unsigned total, float beta, float* out3) {
-    __threadfence();
+// order between the kernels.  Called by ONE thread per workgroup.
+// Ordering without device-wide fences (two __threadfence() here were ~3.5 us each, MI355X_MICROARCH.md price list: 7 us
+// of a 12 us single-workgroup CE launch at batch 32): every access to `sums` is a read-modify-write atomic, which
+// executes at the memory side, for every XCD alike.  A workgroup's add RETURNS (s_waitcnt on its result) before it
+// draws its ticket, so the add is performed before the ticket; tickets are performed in ticket order on one word; the
+// last drawer's read-backs are issued after its ticket returned.  Nothing here is handed over through plain stores.
+__device__ __forceinline__ void loss_sum_and_ticket(float* slot, float v, float* sums, unsigned total, float beta,
+                                                    float* out3) {
+    if (v != 0.f) {
+        const float old = atomicAdd(slot, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");  // performed: the returning form has come back
+    }
+    if (!sums) return;
     const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(sums + 4), 1u);
     if (ticket == total - 1) {
-        __threadfence();
         const float pair = atomicAdd(sums + 0, 0.f), ce = atomicAdd(sums + 1, 0.f), kld = atomicAdd(sums + 2, 0.f);
         const float res = pair + ce;
         out3[0] = res + beta * kld;
@@ -135,8 +144,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         float v = red[0] + red[1] + red[2] + red[3];
-        if (v != 0.f) atomicAdd(loss_sum, v);
-        if (sums) loss_ticket(sums, tickets, beta, out3);
+        loss_sum_and_ticket(loss_sum, v, sums, tickets, beta, out3);
     }
     if (dw2_partial) {  // uniform
 #pragma unroll
@@ -303,8 +311,7 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (local != 0.f) atomicAdd(loss_sum, local);
-        if (sums) loss_ticket(sums, tickets, beta, out3);
+        loss_sum_and_ticket(loss_sum, local, sums, tickets, beta, out3);
     }
     if (dw2_partial) {  // uniform; the waves own disjoint hidden units
 #pragma unroll
@@ -578,21 +585,40 @@ __global__ void vertex_ce_final_kernel(const float* __restrict__ logits, int ld,
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     float local = 0.f;
     if (r < R) {
-        const float* x = logits + (long)r * ld;
-        float mx = -INFINITY;
-        for (int t = 0; t < T; ++t) mx = fmaxf(mx, x[t]);
-        float se = 0.f;
-        for (int t = 0; t < T; ++t) se += expf(x[t] - mx);
-        float lse = mx + logf(se);
-        int k0 = ce_off[r], k1 = ce_off[r + 1];
-        float cnt = (float)(k1 - k0);
-        float* d = dlogits + (long)r * Tp;
-        for (int t = 0; t < Tp; ++t) d[t] = t < T ? cnt * expf(x[t] - lse) : 0.f;
-        for (int k = k0; k < k1; ++k) {
-            int tg = ce_tgt[k];
-            local += lse - x[tg];
-            d[tg] -= 1.f;
+        // Tp == ld == 32 (the launcher checks): the row is 8 float4 requested together, everything after that is
+        // register arithmetic (the scalar form was a chain of dependent loads: 12 us for 224 rows at batch 32)
+        float x[32];
+        const float4* xr = reinterpret_cast<const float4*>(logits + (long)r * ld);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = xr[q];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
+        const int k0 = ce_off[r], k1 = ce_off[r + 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) mx = t < T ? fmaxf(mx, x[t]) : mx;
+        float se = 0.f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) se += t < T ? expf(x[t] - mx) : 0.f;  // (in column order, as the scalar form)
+        const float lse = mx + logf(se);
+        const float cnt = (float)(k1 - k0);
+        float d[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) d[t] = t < T ? cnt * expf(x[t] - lse) : 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const int tg = ce_tgt[k];
+            float xt = 0.f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                xt = t == tg ? x[t] : xt;
+                d[t] -= t == tg ? 1.f : 0.f;
+            }
+            local += lse - xt;
+        }
+        float4* dr = reinterpret_cast<float4*>(dlogits + (long)r * Tp);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dr[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
     }
     local = wave_sum(local);
     __shared__ float red[4];
@@ -601,8 +627,7 @@ __global__ void vertex_ce_final_kernel(const float* __restrict__ logits, int ld,
     __syncthreads();
     if (threadIdx.x == 0) {
         float v = red[0] + red[1] + red[2] + red[3];
-        if (v != 0.f) atomicAdd(sums + 1, v);
-        loss_ticket(sums, tickets, beta, out3);
+        loss_sum_and_ticket(sums + 1, v, sums, tickets, beta, out3);
     }
 }
 
@@ -765,7 +790,8 @@ int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float 
 int vertex_ce_blocks(int R) { return cdiv(R, 256); }
 int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* ce_tgt, float* dlogits, float* sums,
                     unsigned tickets, float beta, float* out3, int R, int T, int Tp, hipStream_t s) {
-    DVAE_REQUIRE(R > 0 && T > 0 && T <= Tp && ld >= T, "vertex_ce: bad R/T/Tp/ld");
+    DVAE_REQUIRE(R > 0 && T > 0 && T <= Tp && Tp == 32 && ld == 32, "vertex_ce_final: needs 0 < T <= Tp == ld == 32 (R=%d T=%d Tp=%d ld=%d)", R, T, Tp, ld);
+    DVAE_REQUIRE(((uintptr_t)logits % 16) == 0 && ((uintptr_t)dlogits % 16) == 0, "vertex_ce_final: logits / dlogits must be 16-byte aligned");
     hipLaunchKernelGGL(vertex_ce_final_kernel, dim3(vertex_ce_blocks(R)), dim3(256), 0, s, logits, ld, ce_off, ce_tgt, dlogits,
                        sums, tickets, beta, out3, R, T, Tp);
     DVAE_LAUNCH_CHECK();

