@@ -593,20 +593,25 @@ int enc_chain_fwd(const EncChainArgs& a, hipStream_t s) {
 //   tile order: gemm_common.h's XCD-aware order (an XCD's 32 tiles = 8 row tiles x 4 hidden tiles share its L2).
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
-constexpr int HBM_ROWS = 128, HBH = 64, HBK = 64, HLD = HBK + 8;
+//   RB (round 3): 32-row blocks per wave.  RB = 2 is the tile above (128 rows, 92-98 KB of LDS: ONE workgroup per CU, whose
+//              tail -- 12-34 us of loads / stores with the matrix unit idle -- nothing overlaps).  RB = 1 is a 64-row tile:
+//              74 KB of LDS and at most 128 registers, so TWO workgroups share a CU and one's tail runs under the other's
+//              K loop (twice the workgroups, each re-reading the weight panel: more L2 -> LDS bytes per flop).
+constexpr int HBH = 64, HBK = 64, HLD = HBK + 8;
 
-template <int NGATE>
+template <int NGATE, int RB>
 struct ChainBf16Lds {
-    static constexpr int A_ELEMS = HBM_ROWS * HLD, STAGE = A_ELEMS + NGATE * HBH * HLD;  // bf16 elements
-    static constexpr int XCH_BYTES = 4 * 8 * NGATE * 64 * 16;  // 4 (hidden half, row block) regions of chain_epilogue<KS = 2>
+    static constexpr int ROWS = 64 * RB;
+    static constexpr int A_ELEMS = ROWS * HLD, STAGE = A_ELEMS + NGATE * HBH * HLD;  // bf16 elements
+    static constexpr int XCH_BYTES = 2 * RB * 8 * NGATE * 64 * 16;  // 2 RB (hidden half, row block) regions of chain_epilogue<KS = 2>
     static constexpr int BYTES = 2 * STAGE * 2 > XCH_BYTES ? 2 * STAGE * 2 : XCH_BYTES;
 };
 
-template <int NGATE, int TAIL>
-__global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const uint16_t* __restrict__ Wh, int ldwh) {
-    using LD = ChainBf16Lds<NGATE>;
-    constexpr int A_ELEMS = LD::A_ELEMS, STAGE = LD::STAGE;
-    constexpr int AU = HBM_ROWS * HBK / 4 / 512;    // float4 units of A per thread (4)
+template <int NGATE, int TAIL, int RB>
+__global__ __launch_bounds__(512, RB == 1 ? 2 : 1) void chain_bf16_kernel(ChainParams p, const uint16_t* __restrict__ Wh, int ldwh) {
+    using LD = ChainBf16Lds<NGATE, RB>;
+    constexpr int A_ELEMS = LD::A_ELEMS, STAGE = LD::STAGE, HBM_ROWS = LD::ROWS;
+    constexpr int AU = HBM_ROWS * HBK / 4 / 512;    // float4 units of A per thread (2 RB)
     constexpr int BU = NGATE * HBH * HBK / 8 / 512;  // 16-byte units of W per thread (one per gate)
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LD::BYTES];
     __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
@@ -615,9 +620,9 @@ __global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const ui
     int m0, n0;
     tile_origin<HBM_ROWS, HBH>(blockIdx.x, p.tiles_x, p.tiles_x * p.tiles_y, m0, n0);
 
-    f32x16 acc[2][NGATE];
+    f32x16 acc[RB][NGATE];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < NGATE; ++i)
 #pragma unroll
@@ -669,15 +674,15 @@ __global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const ui
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int kc = (2 * (2 * kq + s2) + h) * 8;  // this wave's 16-k group 2 kq + s2 of the step, lane half h
-            cbf16x8 af[2], bf[NGATE];
+            cbf16x8 af[RB], bf[NGATE];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                af[rb] = *reinterpret_cast<const cbf16x8*>(a_l + (wm * 64 + rb * 32 + (lane & 31)) * HLD + kc);
+            for (int rb = 0; rb < RB; ++rb)
+                af[rb] = *reinterpret_cast<const cbf16x8*>(a_l + (wm * 32 * RB + rb * 32 + (lane & 31)) * HLD + kc);
 #pragma unroll
             for (int i = 0; i < NGATE; ++i)
                 bf[i] = *reinterpret_cast<const cbf16x8*>(b_l + (i * HBH + wn * 32 + (lane & 31)) * HLD + kc);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int i = 0; i < NGATE; ++i)  // operands swapped: a lane holds 4 consecutive hidden units of one row per quad
                     if (!(CHAIN_ABL & 2)) acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[i], af[rb], acc[rb][i], 0, 0, 0);
@@ -705,9 +710,9 @@ __global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const ui
     if (t < nk) step(IC<1>{}, t);
     // the K halves meet in chain_epilogue: one exchange region per (hidden half, row block)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        float* region = reinterpret_cast<float*>(lds_raw) + (wn * 2 + rb) * (8 * NGATE * 64 * 4);
-        const int mb = m0 + wm * 32 + rb * 32;  // chain_epilogue adds wm * 32: rows m0 + wm * 64 + rb * 32 ..
+    for (int rb = 0; rb < RB; ++rb) {
+        float* region = reinterpret_cast<float*>(lds_raw) + (wn * RB + rb) * (8 * NGATE * 64 * 4);
+        const int mb = m0 + wm * 32 * (RB - 1) + rb * 32;  // chain_epilogue adds wm * 32: rows m0 + wm * 32 RB + rb * 32 ..
         if (kq == 0) chain_epilogue<NGATE, TAIL, 2, 0, false>(p, acc[rb], region, mb, n0 + wn * 32, wm, lane);
         else chain_epilogue<NGATE, TAIL, 2, 1, false>(p, acc[rb], region, mb, n0 + wn * 32, wm, lane);
     }
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(512) void chain_bf16_kernel(ChainParams p, const ui
 bool chain_bf16_ok(int rows, int Hp) {
     static const int knob = [] { const char* v = getenv("DVAE_CHAIN_BF16"); return v ? atoi(v) : 0; }();
     if (!knob || Hp % HBH != 0 || rows < 1) return false;
-    return knob == 2 || (long)cdiv(rows, HBM_ROWS) * (Hp / HBH) >= 192;
+    return knob == 2 || (long)cdiv(rows, 128) * (Hp / HBH) >= 192;
 }
 
 // The packed weights of the bf16-mode call in progress on this thread (set by the orchestration's entry points, orch.h:
@@ -763,11 +768,16 @@ template <int NGATE, int TAIL>
 static int chain_bf16_launch(ChainParams p, const uint16_t* wh, int ldwh, hipStream_t s) {
     DVAE_REQUIRE(p.Hp % HBH == 0 && p.K % HBK == 0 && p.K >= HBK, "bf16 chain level: Hp and K must be multiples of 64 (Hp=%d K=%d)", p.Hp, p.K);
     DVAE_REQUIRE(wh && ((uintptr_t)wh % 16) == 0 && ldwh % 8 == 0 && ldwh >= p.K, "bf16 chain level: the bf16 weight needs 16-byte aligned rows of at least K elements");
+    // DVAE_CHAIN_BF16_ROWS = 64 (default: two workgroups per CU) or 128 (round 2's tile, one per CU)
+    static const int knob_rows = [] { const char* v = getenv("DVAE_CHAIN_BF16_ROWS"); return v ? atoi(v) : 64; }();
+    const int rows = knob_rows == 128 ? 128 : 64;
     p.tiles_x = p.Hp / HBH;
-    p.tiles_y = cdiv(p.M, HBM_ROWS);
+    p.tiles_y = cdiv(p.M, rows);
     static const int knob_log = [] { const char* v = getenv("DVAE_GEMM_LOG"); return v ? atoi(v) : 0; }();
-    if (knob_log) fprintf(stderr, "CHAINSEL chain_bf16_kernel<%d, %d> %d %d %d\n", NGATE, TAIL, p.M, NGATE * p.Hp, p.K);
-    hipLaunchKernelGGL((chain_bf16_kernel<NGATE, TAIL>), dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(512), 0, s, p, wh, ldwh);
+    if (knob_log) fprintf(stderr, "CHAINSEL chain_bf16_kernel<%d, %d, %d rows> %d %d %d\n", NGATE, TAIL, rows, p.M, NGATE * p.Hp, p.K);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y));
+    if (rows == 128) hipLaunchKernelGGL((chain_bf16_kernel<NGATE, TAIL, 2>), grid, dim3(512), 0, s, p, wh, ldwh);
+    else hipLaunchKernelGGL((chain_bf16_kernel<NGATE, TAIL, 1>), grid, dim3(512), 0, s, p, wh, ldwh);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
