@@ -212,6 +212,7 @@ class DVAE(nn.Module):
         self._pw_dirty = False
         self._pw_holders = None  # weak set of the autograd contexts that still read self._pw in their backward pass
         self._named_cache = None
+        self._host_cache = {}  # derived from _named_cache: parameter lists per name list, validated .grad tensors (dropped with it)
         self._grad_sink = getattr(self, "_grad_sink", False)
         self._reducer = getattr(self, "_reducer", None)
         self._enc_names = _ENC_FWD + (_ENC_BWD if self.bidir else [])
@@ -221,6 +222,7 @@ class DVAE(nn.Module):
     def __setattr__(self, name, value):
         if isinstance(value, (nn.Module, nn.Parameter)):
             self.__dict__["_named_cache"] = None  # a (re)assigned sub-module changes the parameter set
+            self.__dict__["_host_cache"] = {}
         super(DVAE, self).__setattr__(name, value)
 
     def _named(self):
@@ -228,15 +230,23 @@ class DVAE(nn.Module):
         times per step); dropped when modules are converted / re-assigned."""
         if self._named_cache is None:
             self._named_cache = dict(self.named_parameters())
+            self._host_cache = {}
         return self._named_cache
 
     def _param_table(self):
         named = self._named()
-        return [named.get(k) for k in PARAM_NAMES]
+        t = self._host_cache.get("table")
+        if t is None:
+            t = self._host_cache["table"] = [named.get(k) for k in PARAM_NAMES]
+        return t
 
     def _hot_params(self, names):
         named = self._named()
-        return [named[k] for k in names]
+        key = ("hot", id(names))
+        t = self._host_cache.get(key)
+        if t is None:
+            t = self._host_cache[key] = [named[k] for k in names]
+        return t
 
     def _pw_hold(self, pw, ctx):
         """`ctx` (an autograd context of _EncodeFn / _LossFn) reads the packed buffer `pw` again in its backward
@@ -260,9 +270,13 @@ class DVAE(nn.Module):
         for its backward pass (`_pw_hold`): then a fresh one is built."""
         lib = _lib.load()
         table = self._param_table()
-        first = next(p for p in table if p is not None)
+        live = self._host_cache.get("live")
+        if live is None:
+            live = self._host_cache["live"] = [p for p in table if p is not None]
+        first = live[0]
         _require_gpu(first, "DVAE")
-        key = tuple((p.data_ptr(), p._version) if p is not None else None for p in table)
+        # (two flat lists, compared as lists: this runs twice per train step and the host is the bound at batch 32)
+        key = ([p.data_ptr() for p in live], [p._version for p in live], [p is None for p in table])
         if self._pw is not None and key == self._pw_key and not self._pw_dirty and self._pw.device == first.device:
             return self._pw
         if self._n_packed is None:
@@ -276,7 +290,7 @@ class DVAE(nn.Module):
         # same set of parameters as the buffer was packed from (absent ones leave zeros), and no autograd graph that
         # was built on it still waits for its backward pass
         reuse = (self._pw is not None and self._pw.device == first.device and self._pw_key is not None and
-                 [k is None for k in key] == [k is None for k in self._pw_key] and not self._pw_holders)
+                 key[2] == self._pw_key[2] and not self._pw_holders)
         if reuse:
             _lib.check(lib.dvae_repack_weights(C.byref(self._desc), arr, self._pw.data_ptr(), _stream()), "dvae_repack_weights")
         else:
@@ -294,10 +308,25 @@ class DVAE(nn.Module):
         accumulation kernels of its own."""
         lib = _lib.load()
         named = self._named()
+        sink = self._grad_sink
+        if sink:
+            # fast path: the same .grad tensors as at the last call (identity), validated then: reuse the pointer arrays
+            c = self._host_cache.get(("unpack", id(names)))
+            if c is not None and c[4] == pg.device:
+                params, gs = c[0], c[1]
+                for i in range(len(params)):
+                    if params[i].grad is not gs[i]:
+                        c = None
+                        break
+            if c is not None and c[4] == pg.device:
+                if self._reducer is not None:
+                    self._reducer.clean = False  # the flat gradient buffer is about to be added to
+                _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), c[2], c[3], 1, _stream()),
+                           "dvae_unpack_grads")
+                return c[5]
         ptrs = [None] * _lib.NUM_PARAMS
         want = [0] * _lib.NUM_PARAMS
         grads = []
-        sink = self._grad_sink
         for k in names:
             if sink:
                 g = named[k].grad
@@ -315,6 +344,9 @@ class DVAE(nn.Module):
         w = (C.c_uint8 * _lib.NUM_PARAMS)(*want)
         _lib.check(lib.dvae_unpack_grads(C.byref(self._desc), pw.data_ptr(), pg.data_ptr(), arr, w, int(bool(sink)),
                                          _stream()), "dvae_unpack_grads")
+        if sink:
+            params = [named[k] for k in names]
+            self._host_cache[("unpack", id(names))] = (params, [p.grad for p in params], arr, w, pg.device, grads)
         return grads
 
     def attach_grad_sink(self, on=True, reducer=None):

@@ -25,7 +25,8 @@ shutil.copy(os.path.join(P, "stats_bf16", "s_kernel_stats.csv"), os.path.join(D,
 for f in ("gemm_shapes_fp32.txt", "gemm_shapes_bf16.txt", "phase_times_cfg2.txt", "launch_log_cfg2.txt",
           "phase_times_cfg5_bf16.txt", "host_cost_cfg1.txt", "gemm_shapes_bf16_f32xf32.txt", "gemm_shapes_bf16_f32xbf16.txt",
           "gemm_shapes_bf16_bf16xbf16.txt", "epoch_b32_cfg1.txt", "epoch_b32_cfg2.txt", "epoch_b1024_cfg2.txt",
-          "wgrad_bf16_256.txt", "wgrad_bf16_128.txt", "chain_bf16_levels.txt", "cfg5_bf16_kernel_stats.csv"):
+          "wgrad_bf16_256.txt", "wgrad_bf16_128.txt", "cfg5_bf16_kernel_stats.csv", "gemm_skinny.txt",
+          "host_profile_cfg1.txt", "timeline_cfg1.txt", "timeline_cfg5_bf16_by_kernel.txt", "cfg1_kernel_stats.csv", "chain_level_alone_kernel_stats.csv"):
     if not os.path.exists(os.path.join(P, f)):
         continue
     txt = "".join(l for l in open(os.path.join(P, f)) if "amdgpu.ids" not in l)

@@ -35,3 +35,15 @@ cp $R/gpurun_out/kstats/cfg5_bf16/s_kernel_stats.csv $O/cfg5_bf16_kernel_stats.c
 timeout -k 10 200 python tools/epoch_bench.py 17118 32 cfg1 > $O/epoch_b32_cfg1.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/epoch_bench.py 17118 32 cfg2 > $O/epoch_b32_cfg2.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/epoch_bench.py 17118 1024 cfg2 > $O/epoch_b1024_cfg2.txt 2>&1 || exit 1
+# 6. round 3: the batch-32 path (small-M product kernel, persistent chains, host side)
+timeout -k 10 200 python tools/gemm_skinny_bench.py > $O/gemm_skinny.txt 2>&1 || exit 1
+timeout -k 10 200 python tools/host_profile.py cfg1 300 > $O/host_profile_cfg1.txt 2>&1 || exit 1
+bash tools/timeline.sh gpurun_out/prof/timeline_cfg1.txt --config cfg1 --steps 10 --warmup 5 || exit 1
+bash tools/timeline.sh gpurun_out/prof/timeline_cfg5_bf16.txt --config cfg5 --dtype bf16 --steps 3 --warmup 2 || exit 1
+python3 tools/timeline_agg.py $O/timeline_cfg5_bf16.txt 45 > $O/timeline_cfg5_bf16_by_kernel.txt || exit 1
+bash tools/kstats.sh cfg1 --config cfg1 --steps 100 --warmup 10 > $O/kstats_cfg1.txt 2>&1 || exit 1
+cp $R/gpurun_out/kstats/cfg1/s_kernel_stats.csv $O/cfg1_kernel_stats.csv || exit 1
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain_alone -o s -- python3 $R/tools/chain_bench.py 1024 512 > $O/chain_alone.log 2>&1 || exit 1
+cp $O/chain_alone/s_kernel_stats.csv $O/chain_level_alone_kernel_stats.csv || exit 1
+cd $R

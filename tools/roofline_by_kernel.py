@@ -84,6 +84,14 @@ def main():
         flop[fam] += 2.0 * M * N * K
         launches[fam] += 1
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_bench_cfg2_kernel_stats.csv" % r))))
+    # kernels the profiled command ALSO runs on their own (bench.py's roofline legs): their average duration alone, from
+    # the rocprofv3 stats of tools/chain_bench.py (profiles/rNN_chain_level_alone_kernel_stats.csv), to take those
+    # launches out of the in-step figures
+    alone = {}
+    ap = os.path.join(ROOT, "profiles", "%s_chain_level_alone_kernel_stats.csv" % r)
+    if os.path.exists(ap):
+        for x in csv.DictReader(open(ap)):
+            alone[x["Name"]] = float(x["AverageNs"])
     total_ns = sum(float(x["TotalDurationNs"]) for x in rows)
     fams = collections.OrderedDict()
     for x in rows:
@@ -95,8 +103,13 @@ def main():
         if key is None:
             key = re.sub(r"\(.*", "", name)
         e = fams.setdefault(key, dict(ns=0.0, calls=0))
-        e["ns"] += float(x["TotalDurationNs"])
-        e["calls"] += int(x["Calls"])
+        ns, calls = float(x["TotalDurationNs"]), int(x["Calls"])
+        if key in flop and x["Name"] in alone and calls > steps * launches[key]:
+            extra = calls - steps * launches[key]  # the roofline leg's launches of this kernel
+            ns -= extra * alone[x["Name"]]
+            calls -= extra
+        e["ns"] += ns
+        e["calls"] += calls
     out = dict(workload="cfg2 fp32, bench.py train step", steps_in_profile=steps, peak_tflops=PEAK,
                kernel_ms_per_step=total_ns / steps / 1e6, families=[])
     for k, e in sorted(fams.items(), key=lambda kv: -kv[1]["ns"]):
