@@ -500,6 +500,12 @@ static int wbl_split() {
     static const int knob = [] { const char* v = getenv("DVAE_WBL_SPLIT"); return v ? atoi(v) : 0; }();
     return knob;
 }
+// DVAE_WBL_GROUP=g: the decoder's per-level weight-gradient terms are issued for g finished levels at a time (their
+// rows are contiguous): g times fewer launches, g times longer K per workgroup, the side stream g - 1 levels later
+static int wbl_group() {
+    static const int knob = [] { const char* v = getenv("DVAE_WBL_GROUP"); return v ? atoi(v) : 1; }();
+    return knob < 1 ? 1 : knob;
+}
 
 // level-major batches (every graph full size: all of the reference's data sets) run the loss forward's per-level
 // predictor products beside the chain
@@ -1144,6 +1150,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             DVAE_TRY(fork_side(side_guard));
             DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2));
         }
+        int pend_h = 0, pend_g = 0;  // finished levels whose weight-gradient terms are not issued yet (wbl_group)
+        long lo_g = 0;
         for (int v = n - 1; v >= 0 && !tiny; --v) {
             const long r0 = (long)v * B;
             float* dst = w.dst + r0 * Hp;
@@ -1178,11 +1186,19 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             if (wbl) {
                 // final now: d gh of vertex v, and d gm of vertex v - 1 (fused: the tail above) or v (unfused: this iteration)
                 const int vg = fused ? v - 1 : v;
-                DVAE_TRY(fork_side(side_guard));
-                DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + B, s2, wbl_split()));
-                if (vg >= 0 && vg < n - 1)  // (d gm of the last vertex is zero: no message leaves it)
-                    DVAE_TRY(lin_wgrad(w.dgm + (size_t)vg * B * 2 * Hp, 2 * Hp, w.st + (size_t)vg * B * Hp, Hp, nullptr,
-                                       pg + L.wgm[0], Hp, B, 2 * Hp, Hp, s2, 0, wbl_split()));
+                ++pend_h;  // levels v .. v + pend_h - 1
+                if (vg >= 0 && vg < n - 1) {  // (d gm of the last vertex is zero: no message leaves it)
+                    ++pend_g;  // levels vg .. vg + pend_g - 1
+                    lo_g = vg;
+                }
+                if (pend_h >= wbl_group() || v == 0) {
+                    DVAE_TRY(fork_side(side_guard));
+                    DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + (long)pend_h * B, s2, wbl_split()));
+                    if (pend_g > 0)
+                        DVAE_TRY(lin_wgrad(w.dgm + (size_t)lo_g * B * 2 * Hp, 2 * Hp, w.st + (size_t)lo_g * B * Hp, Hp, nullptr,
+                                           pg + L.wgm[0], Hp, pend_g * B, 2 * Hp, Hp, s2, 0, wbl_split()));
+                    pend_h = pend_g = 0;
+                }
             }
         }
     }

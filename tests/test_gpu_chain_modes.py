@@ -44,13 +44,16 @@ def test_parity_with_fused_level_kernels_forced(extra):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-def test_bf16_parity_with_bf16_level_kernels_forced():
-    """The bf16 level kernels (chain_bf16_kernel; off by default inside the train step) forced for every level size
+@pytest.mark.parametrize("rows", ["64", "128"])
+def test_bf16_parity_with_bf16_level_kernels_forced(rows):
+    """(rows: the kernels' row tile, DVAE_CHAIN_BF16_ROWS: 64 = two workgroups per CU, the launch default; 128 = round 2's.)
+    The bf16 level kernels (chain_bf16_kernel; off by default inside the train step) forced for every level size
     (DVAE_CHAIN_BF16=2): the bf16-mode parity cases must hold with them -- the orchestration then finds the bf16 weight
     copies (straight for the forward operations, transposed for the backward ones) through the call's context."""
-    env = dict(os.environ, DVAE_CHAIN_BF16="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "cfg5_shape_bf16_mode_close_to_oracle or bf16_mode_close_to_oracle", "-p", "no:cacheprovider",
+    env = dict(os.environ, DVAE_CHAIN_BF16="2", DVAE_CHAIN_BF16_ROWS=rows)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), os.path.join("tests", "test_gpu_chain_bf16.py"),
+                        "-q", "-x", "-m", "gpu",
+                        "-k", "cfg5_shape_bf16_mode_close_to_oracle or bf16_mode_close_to_oracle or chain_bf16", "-p", "no:cacheprovider",
                         "--timeout", "120", "--timeout-method", "thread"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
