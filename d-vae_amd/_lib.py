@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32),
                 ("act", C.c_int32), ("accumulate", C.c_int32), ("relu_mask", C.c_void_p),
-                ("b_rows_bound", C.c_int32), ("a_bf16", C.c_int32), ("b_bf16", C.c_int32)]
+                ("b_rows_bound", C.c_int32), ("a_bf16", C.c_int32), ("b_bf16", C.c_int32), ("c_bf16", C.c_int32)]
 
 
 class DvaeHipError(RuntimeError):

@@ -441,7 +441,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
     static const int knob_log = env_int("DVAE_GEMM_LOG"), knob_tile = env_int("DVAE_GEMM_TILE"),
                      knob_split = env_int("DVAE_GEMM_SPLIT");
     DVAE_TRY(gemm_check(d, 32));
-    DVAE_REQUIRE(!d.a_bf16 && !d.b_bf16, "gemm_f32: bf16-stored operands belong to dvae_gemm_bf16");
+    DVAE_REQUIRE(!d.a_bf16 && !d.b_bf16 && !d.c_bf16, "gemm_f32: bf16-stored operands / outputs belong to dvae_gemm_bf16");
     if (knob_log)
         fprintf(stderr, "GEMM %d %d %d akm=%d bkm=%d acc=%d bias=%d act=%d ar=%d br=%d cr=%d\n", d.M, d.N, d.K, d.a_kmajor,
                 d.b_kmajor, d.accumulate, d.bias != nullptr, d.act, d.a_rows != nullptr, d.b_rows != nullptr,
@@ -468,7 +468,7 @@ int gemm(const dvae_gemm_desc& d, hipStream_t s, int max_split) {
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;
     p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
-    p.split_k = 1; p.k_per_split = 0;
+    p.split_k = 1; p.k_per_split = 0; p.c_bf16 = 0;
     if (d.K == 0) {
         // empty contraction: result is bias/act only; run with kend == 0
     }

@@ -288,7 +288,8 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     {   // two K-contiguous operands, bf16- or fp32-stored: the large-tile kernels of gemm_bf16_nn.hip
         const int rc = gemm_bf16_nn(d, s);
         if (rc <= 0) return rc;
-        if (d.a_bf16 || d.b_bf16) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands must be K-contiguous");
+        if (d.a_bf16 || d.b_bf16 || d.c_bf16)
+            return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands / outputs need two K-contiguous operands");
     }
     dvae_gemm_desc sub;
     int k0 = 0;
@@ -305,7 +306,7 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;
     p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
-    p.split_k = 1; p.k_per_split = 0;
+    p.split_k = 1; p.k_per_split = 0; p.c_bf16 = 0;
     // Tile / split-K choice: as for the fp32 kernel.  A bf16 K step is 16x cheaper on the matrix
     // pipe, so these products are bound by operand traffic and launch latency: prefer many
     // workgroups (two or more per CU) over long K loops.

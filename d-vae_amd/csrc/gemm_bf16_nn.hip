@@ -173,7 +173,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nn_kernel(GemmParams p
             __syncthreads();
             cur ^= 1;
         }
-        store_acc<TM, TN, SWAP>(p, acc, m0, n0, wm, wn, lane, BM, BN);
+        if (p.c_bf16) store_acc_bf16<TM, TN>(p, acc, m0, n0, wm, wn, lane, BM, BN);
+        else store_acc<TM, TN, SWAP>(p, acc, m0, n0, wm, wn, lane, BM, BN);
     }
 }
 
@@ -205,7 +206,11 @@ static int launch_nn(GemmParams p, bool ah, bool bh, int cus, hipStream_t s) {
 int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
     if (d.a_kmajor || d.b_kmajor) return 1;
     static const int knob = getenv("DVAE_GEMM_NN") ? atoi(getenv("DVAE_GEMM_NN")) : 1;  // 0: never, 64 / 128 / 256: force the tile
-    const bool typed = d.a_bf16 || d.b_bf16;
+    const bool typed = d.a_bf16 || d.b_bf16 || d.c_bf16;
+    if (d.c_bf16)
+        DVAE_REQUIRE(!d.accumulate && d.act == 0 && !d.relu_mask && d.ldc % 4 == 0 && (uintptr_t)d.C % 8 == 0 && d.N % 4 == 0 &&
+                         ((uintptr_t)d.bias % 16) == 0,
+                     "gemm_bf16: a bf16-stored C takes no activation / accumulate / mask and needs 8-byte aligned rows, N %% 4 == 0");
     if (!knob && !typed) return 1;
     const int ea = d.a_bf16 ? 8 : 4, eb = d.b_bf16 ? 8 : 4;
     DVAE_REQUIRE(d.K % ea == 0 && d.lda % ea == 0 && (uintptr_t)d.A % 16 == 0, "gemm_bf16: A needs 16-byte aligned rows and K %% %d == 0", ea);
@@ -227,8 +232,8 @@ int gemm_bf16_nn(const dvae_gemm_desc& d, hipStream_t s) {
     p.a_rows = d.a_rows; p.b_rows = d.b_rows; p.c_rows = d.c_rows;
     p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
-    p.split_k = 1; p.k_per_split = 0;
-    if (d.b_rows || !gemm_vec_epilogue_ok(p)) {  // not built here: a gathered B, an output that cannot take 16-byte stores
+    p.split_k = 1; p.k_per_split = 0; p.c_bf16 = d.c_bf16;
+    if (d.b_rows || (!d.c_bf16 && !gemm_vec_epilogue_ok(p))) {  // not built here: a gathered B, an output that cannot take 16-byte stores
         if (typed) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands need N %% 4 == 0, ldc %% 4 == 0, 16-byte aligned C / bias, no b_rows");
         return 1;
     }

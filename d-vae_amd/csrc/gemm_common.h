@@ -22,6 +22,7 @@ struct GemmParams {
     int split_k;     // >1: atomicAdd into C (C must hold the running sum / zeros)
     int k_per_split; // multiple of the kernel's K step
     int tiles_x, tiles_y;  // output tiles along N and M; workgroup w walks tiles w, w + gridDim.x, ...
+    int c_bf16;            // gemm_bf16_nn only: C is stored as bf16 (ldc in bf16 elements)
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own
@@ -126,6 +127,39 @@ __device__ __forceinline__ void store_acc(const GemmParams& p, f32x16 (&acc)[TM]
                     }
                     *dst = v;
                 }
+            }
+        }
+    }
+}
+
+// The SWAP epilogue for a C stored as bf16 (gemm_bf16_nn.hip, dvae_gemm_desc.c_bf16): a register quad = 4 consecutive
+// columns of one row = one 8-byte store of 4 bf16 (round to nearest even); bias and row scatter as above, nothing else.
+template <int TM, int TN>
+__device__ __forceinline__ void store_acc_bf16(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                               int lane, int BM, int BN) {
+    typedef __bf16 sbf16x4 __attribute__((ext_vector_type(4)));
+    const int h = lane >> 5, cl = lane & 31;
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+    uint16_t* Ch = reinterpret_cast<uint16_t*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + (wm * TM + i) * 32 + cl;
+        if (!(interior || row < p.M)) continue;
+        const long crow = p.c_rows ? (long)p.c_rows[row] : (long)row;
+        uint16_t* drow = Ch + crow * p.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + (wn * TN + j) * 32 + 8 * q + 4 * h;
+                if (!(interior || col < p.N)) continue;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (p.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                const sbf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<uint2*>(drow + col) = __builtin_bit_cast(uint2, o);
             }
         }
     }

@@ -193,7 +193,7 @@ int gemm_skinny(const dvae_gemm_desc& d, hipStream_t s, int force_nt) {
     const int knob_m = g_skinny_mmac;
     static const int knob_nt = [] { const char* v = getenv("DVAE_GEMM_SKINNY_NT"); return v ? atoi(v) : 0; }();
     static const int knob_log = [] { const char* v = getenv("DVAE_GEMM_LOG"); return v ? atoi(v) : 0; }();
-    if ((!force_nt && (double)d.M * d.N * d.K > 1e6 * knob_m) || d.a_kmajor || d.b_rows || d.a_bf16 || d.b_bf16 || d.M <= 0 || d.N <= 0) return 1;
+    if ((!force_nt && (double)d.M * d.N * d.K > 1e6 * knob_m) || d.a_kmajor || d.b_rows || d.a_bf16 || d.b_bf16 || d.c_bf16 || d.M <= 0 || d.N <= 0) return 1;
     if (d.K < 16 || d.K % 16 || d.N % 4 || d.ldc % 4 || d.lda % 4 || d.ldb % 4) return 1;
     if ((uintptr_t)d.A % 16 || (uintptr_t)d.B % 16 || (uintptr_t)d.C % 16 || (uintptr_t)d.bias % 16 || (uintptr_t)d.relu_mask % 16) return 1;
     if (d.b_kmajor && d.N < 4) return 1;
@@ -202,7 +202,7 @@ int gemm_skinny(const dvae_gemm_desc& d, hipStream_t s, int force_nt) {
     p.a_rows = d.a_rows; p.b_rows = nullptr; p.c_rows = d.c_rows;
     p.bias = d.bias; p.relu_mask = d.relu_mask; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.accumulate = d.accumulate;
-    p.split_k = 1; p.k_per_split = 0;
+    p.split_k = 1; p.k_per_split = 0; p.c_bf16 = 0;
     // blocks per tile: as many workgroups as the product has 16 x 16 blocks until that is more than the chip holds at
     // once (a tile of NT blocks re-reads its A rows once instead of NT times)
     const long blocks = (long)cdiv(d.M, 16) * cdiv(d.N, 16);

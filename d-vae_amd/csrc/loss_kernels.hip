@@ -168,7 +168,48 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
 // values (relu outputs for the w2 gradient, mask words) take 230 VGPRs: two waves per SIMD, each waiting on its own 64
 // loads -- the kernel ran at a fraction of the L2 rate (cfg 5: 22.6 ms for 4.1 M pairs).  A quarter row per wave is
 // ~70 VGPRs; the four partial sums of a pair meet through LDS (one barrier per pair, double-buffered slots).
-template <int NITW>
+// TH (round 3, bf16 mode): the two tables are stored as bf16 (written so by the products that make them: half the
+// bytes written, half the L2 bytes read here, and the two held rows take 16 registers instead of 32); `ea` / `eb` then
+// point at bf16 words, rows HEp ELEMENTS apart, and the first layer's bias b1 is already IN the EB table (the product that
+// makes it adds it in its epilogue; the table's no-input row holds b1): 16 registers and an add per unit less here
+// (106 -> 90 registers: five workgroups per CU instead of four).  w2, the sums and the masks stay fp32.
+__device__ __forceinline__ float4 bf16x4_to_f4(uint2 r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+template <bool TH>
+struct PairRow;
+template <>
+struct PairRow<false> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* tab, long row, int HEp, int c) { v = ld4c(tab + row * HEp + c); }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ float4 get() const { return v; }
+};
+template <>
+struct PairRow<true> {
+    uint2 v;
+    __device__ __forceinline__ void load(const float* tab, long row, int HEp, int c) {
+        v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(tab) + row * HEp + c);
+    }
+    __device__ __forceinline__ void zero() { v = make_uint2(0u, 0u); }
+    __device__ __forceinline__ float4 get() const { return bf16x4_to_f4(v); }
+};
+// FULL: HEp == 1024 NITW (cfg 5: 4096), no unit of any lane lies past the row: the per-iteration range checks (an exec-mask
+// branch each) are compiled out.
+// The loop is bound by VECTOR INSTRUCTIONS, not by bytes or latency (round 3, counted in the ISA: ~330 per pair and wave
+// = 1320 issue cycles per SIMD, and the measured 1.8 pairs per us and CU is exactly one pair per 1320 cycles; neither a
+// 2x larger grid, nor five instead of four workgroups per CU, nor half the table bytes moved it): hence ReLU and mask
+// bit from ONE compare (fmaxf costs a canonicalising max besides), the held EB row converted once per row instead of
+// once per pair, no bias / third-table arithmetic where the template says there is none, the two logarithms of the loss
+// in the one thread that uses them.
+// Diagnostic builds only (tools/pair_ablate.sh; results are wrong, only the time matters): PAIR_ABL bit 0 loads every
+// pair's rows from row 0 (always L1 / L2 hits), bit 1 skips the cross-wave exchange and its barrier, bit 2 skips the mask
+// store, bit 3 skips the w2-gradient accumulation, bit 4 skips the table row loads altogether.
+#ifndef PAIR_ABL
+#define PAIR_ABL 0
+#endif
+template <int NITW, bool TH, bool FULL>
 __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __restrict__ ea, const float* __restrict__ eb,
                                                              const float* __restrict__ ec, const int* __restrict__ pair_a,
                                                              const int* __restrict__ pair_h, const int* __restrict__ pair_c,
@@ -187,11 +228,16 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
         for (int c = threadIdx.x; c < HEp; c += 256) sh[c] = 0.f;
     }
     float* xch = sh + HEp;
+    // the mask halves of a pair's four waves meet here so that waves 0 and 2 store whole words (see the store below)
+    uint16_t* mb = reinterpret_cast<uint16_t*>(xch + 8);  // [2 parities][2 wave pairs][64 lanes][2 halves]
     float local = 0.f;
     const float bias2 = b2[0];
-    float aw[NITW * 4];
+    // (pairs of floats: the w2 sum and the w2-gradient update then compile to packed fp32 multiply-adds, two units per
+    // instruction -- this loop is bound by its vector instruction count)
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    pf2 aw[NITW * 2];
 #pragma unroll
-    for (int i = 0; i < NITW * 4; ++i) aw[i] = 0.f;
+    for (int i = 0; i < NITW * 2; ++i) aw[i] = pf2{0.f, 0.f};
     // pairs of this workgroup.  `group` > 0 (runs of `group` pairs = the pairs of one graph, which share table rows: a
     // graph's pairs touch 1 MB of EA and ~3.6 MB of EB rows at cfg 5, each EB row ~9 times): the workgroups that share
     // an XCD (blockIdx % 8) work through the SAME graph together, pair k of the graph going to workgroup k mod J of the
@@ -204,59 +250,82 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
     // passes a predecessor of v (~9 pairs per row at cfg 5), so a workgroup that walks consecutive pairs keeps the row
     // in registers and reads one table row per pair instead of two (132 -> ~80 GB of L2 reads per pass).
     constexpr int RUN = 16;
-    const int per_graph = coop ? ((group + RUN - 1) / RUN + J - 1) / J * RUN : group;  // iterations a workgroup spends on one graph
-    const int iters = coop ? ((n_groups + 7) / 8) * per_graph
+    // (round 3) the XCD's graphs xcd, xcd + 8, ... form ONE sequence of runs dealt to its J workgroups round-robin, so
+    // no workgroup idles when J exceeds a graph's runs (cfg 5: 126 runs; 160 workgroups per XCD at five per CU) and
+    // the XCD works on at most two consecutive graphs at any moment
+    const int runs = (group + RUN - 1) / RUN;
+    const int graphs_here = coop && xcd < n_groups ? (n_groups - xcd + 7) / 8 : 0;
+    const int iters = coop ? (int)(((long)graphs_here * runs + J - 1) / J) * RUN
                            : group > 0 ? ((n_groups + gridDim.x - 1) / gridDim.x) * group : (n_pairs + gridDim.x - 1) / gridDim.x;
-    uint16_t* mask16 = reinterpret_cast<uint16_t*>(mask);
     int executed = 0, held = -1;  // held: the EB row in `bq`
-    float4 bq[NITW], b1q[NITW], w2q[NITW];  // this wave's quarter of the EB row, of b1 and of w2
+    float4 bq[NITW];              // this wave's quarter of the EB row (bf16 tables: converted when the row is loaded)
+    float4 b1q[NITW], w2q[NITW];  // ... of b1 and of w2
 #pragma unroll
     for (int ii = 0; ii < NITW; ++ii) {
         const int c = lane * 4 + 256 * (wave * NITW + ii);
-        b1q[ii] = c < HEp ? ld4c(b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        w2q[ii] = c < HEp ? ld4c(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TH) b1q[ii] = (FULL || c < HEp) ? ld4c(b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        w2q[ii] = (FULL || c < HEp) ? ld4c(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto pair_of = [&](int it) -> int {  // the pair of iteration `it`, n_pairs when there is none (uniform over the workgroup)
-        if (it >= iters) return n_pairs;
-        int p;
-        if (coop) {
-            const int run = xcd + 8 * (it / per_graph), w = it % per_graph, k = (j + J * (w / RUN)) * RUN + w % RUN;
-            p = (run < n_groups && k < group) ? run * group + k : n_pairs;
-        } else if (group > 0) {
-            const int run = blockIdx.x + (it / group) * gridDim.x;
-            p = run < n_groups ? run * group + it % group : n_pairs;
-        } else {
-            p = blockIdx.x + it * gridDim.x;
+    // The pair of each iteration in turn (n_pairs when there is none; uniform over the workgroup), kept as running
+    // counters: computed from `it` with divisions and remainders it was ~170 scalar instructions per pair and wave --
+    // with 16-20 waves per CU on ONE scalar unit that, not the vector work, set the kernel's rate (cfg 5: 10.1 ms).
+    int nx_it = 0, nx_w = 0, nx_t = j, nx_run = coop ? xcd : (int)blockIdx.x, nx_k = 0;
+    if (coop)
+        while (nx_t >= runs) { nx_t -= runs; nx_run += 8; }
+    auto next_pair = [&]() -> int {
+        int p = n_pairs;
+        if (nx_it < iters) {
+            if (coop) {
+                const int k = nx_t * RUN + nx_w;
+                if (nx_run < n_groups && k < group) p = nx_run * group + k;
+                if (++nx_w == RUN) {
+                    nx_w = 0;
+                    nx_t += J;
+                    while (nx_t >= runs) { nx_t -= runs; nx_run += 8; }
+                }
+            } else if (group > 0) {
+                if (nx_run < n_groups) p = nx_run * group + nx_k;
+                if (++nx_k == group) { nx_k = 0; nx_run += gridDim.x; }
+            } else {
+                p = nx_run;  // every gridDim.x-th pair
+                nx_run += gridDim.x;
+            }
+            if (p > n_pairs) p = n_pairs;
         }
-        return p < n_pairs ? p : n_pairs;
+        ++nx_it;
+        return p;
     };
     // The rows of the NEXT pair are requested as soon as the current pair's have been consumed, into the same
     // registers: their latency (and that of the index loads in front of them) then runs under the current pair's
     // reduction, barrier and loss arithmetic instead of in front of the next pair's (the kernel was bound by that
     // chain -- 3.4 us per pair and workgroup -- not by bytes: halving its L2 reads alone changed nothing).
-    float4 aq[NITW];
+    PairRow<TH> aq[NITW];
     auto fetch = [&](int p) {
-        const float* ra = ea + (long)pair_a[p] * HEp;
+        if (PAIR_ABL & 16) return;
+        const long arow = (PAIR_ABL & 1) ? 0 : pair_a[p];
 #pragma unroll
         for (int ii = 0; ii < NITW; ++ii) {
             const int c = lane * 4 + 256 * (wave * NITW + ii);
-            aq[ii] = c < HEp ? ld4c(ra + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL || c < HEp) aq[ii].load(ea, arow, HEp, c);
+            else aq[ii].zero();
         }
-        const int hrow = pair_h[p];
+        const int hrow = (PAIR_ABL & 1) ? 0 : pair_h[p];
         if (hrow != held) {  // uniform over the workgroup
-            const float* rb = eb + (long)hrow * HEp;
 #pragma unroll
             for (int ii = 0; ii < NITW; ++ii) {
                 const int c = lane * 4 + 256 * (wave * NITW + ii);
-                bq[ii] = c < HEp ? ld4c(rb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                PairRow<TH> t;
+                if (FULL || c < HEp) t.load(eb, hrow, HEp, c);
+                else t.zero();
+                bq[ii] = t.get();
             }
             held = hrow;
         }
     };
-    int p = pair_of(0);
+    int p = next_pair();
     if (p < n_pairs) fetch(p);
     for (int it = 0; it < iters; ++it) {
-        const int pn = pair_of(it + 1);
+        const int pn = next_pair();
         if (p >= n_pairs) {  // uniform over the workgroup
             if (pn < n_pairs) fetch(pn);
             p = pn;
@@ -264,48 +333,80 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
         }
         const float* rc = ec ? ec + (long)pair_c[p] * HEp : nullptr;
         const float t = (float)pair_t[p];
-        float rv[NITW * 4];
+        pf2 rv[NITW * 2];
         uint32_t bits16 = 0u;
-        float s = 0.f;
+        pf2 s2 = pf2{0.f, 0.f};
 #pragma unroll
         for (int ii = 0; ii < NITW; ++ii) {
             const int c = lane * 4 + 256 * (wave * NITW + ii);
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < HEp) {
-                float4 a = aq[ii], b = bq[ii], bb = b1q[ii], w = w2q[ii];
-                float4 pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
-                if (rc) {
-                    float4 cc = ld4c(rc + c);
-                    pre.x += cc.x; pre.y += cc.y; pre.z += cc.z; pre.w += cc.w;
+            if (FULL || c < HEp) {
+                const float4 a = aq[ii].get(), b = bq[ii], w = w2q[ii];
+                float4 pre;
+                if constexpr (TH) {  // (b1 is in the EB table)
+                    pre = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                } else {
+                    const float4 bb = b1q[ii];
+                    pre = make_float4(a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w);
+                    if (rc) {
+                        float4 cc = ld4c(rc + c);
+                        pre.x += cc.x; pre.y += cc.y; pre.z += cc.z; pre.w += cc.w;
+                    }
                 }
-                r = make_float4(fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f));
-                const uint32_t b4 = (pre.x > 0.f ? 1u : 0u) | (pre.y > 0.f ? 2u : 0u) | (pre.z > 0.f ? 4u : 0u) |
-                                    (pre.w > 0.f ? 8u : 0u);
+                // ReLU and its mask bit from one compare (the same values as fmaxf(pre, 0): NaN and -0 give 0)
+                const bool px = pre.x > 0.f, py = pre.y > 0.f, pz = pre.z > 0.f, pw_ = pre.w > 0.f;
+                r = make_float4(px ? pre.x : 0.f, py ? pre.y : 0.f, pz ? pre.z : 0.f, pw_ ? pre.w : 0.f);
+                const uint32_t b4 = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (pw_ ? 8u : 0u);
                 bits16 |= b4 << (4 * ii);
-                s += w.x * r.x + w.y * r.y + w.z * r.z + w.w * r.w;
+                s2 += pf2{w.x, w.y} * pf2{r.x, r.y};
+                s2 += pf2{w.z, w.w} * pf2{r.z, r.w};
             }
-            rv[4 * ii + 0] = r.x; rv[4 * ii + 1] = r.y; rv[4 * ii + 2] = r.z; rv[4 * ii + 3] = r.w;
+            rv[2 * ii + 0] = pf2{r.x, r.y};
+            rv[2 * ii + 1] = pf2{r.z, r.w};
         }
+        float s = s2.x + s2.y;
         if (pn < n_pairs) fetch(pn);  // aq / bq are free again
         s = wave_sum(s);
-        float* slot = xch + 4 * (executed++ & 1);  // (parity of the pairs actually run: skipped iterations take no barrier)
-        if (lane == 0) slot[wave] = s;
-        __syncthreads();  // (the slots of pair it - 1 are free again: every wave passed this barrier after reading them)
-        s = slot[0] + slot[1] + slot[2] + slot[3] + bias2;  // the same order in every wave
-        float prob = 1.f / (1.f + expf(-s));
-        float lp = fmaxf(logf(prob), -100.f);
-        float lq = fmaxf(logf(1.f - prob), -100.f);
-        float pq = prob * (1.f - prob);
-        float g = (prob - t) / fmaxf(pq, 1e-12f) * pq;
+        const int par = executed++ & 1;  // (parity of the pairs actually run: skipped iterations take no barrier)
+        float* slot = xch + 4 * par;
+        if (!(PAIR_ABL & 2)) {
+            if (lane == 0) slot[wave] = s;
+            if (mask) mb[((par * 2 + (wave >> 1)) * 64 + lane) * 2 + (wave & 1)] = (uint16_t)bits16;
+            __syncthreads();  // (the slots of pair it - 1 are free again: every wave passed this barrier after reading them)
+            s = slot[0] + slot[1] + slot[2] + slot[3];  // the same order in every wave
+        }
+        s += bias2;
+        float prob, pq, g;
+        if constexpr (TH) {
+            // bf16 mode: hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each).  Every lane of the workgroup
+            // computes this same scalar, i.e. it costs as many vector instructions as sixteen table units would: the
+            // library routines (~60 instructions) were a fifth of the loop (ablation: profiles/r03_pair_fwd_ablation.txt)
+            prob = __builtin_amdgcn_rcpf(1.f + __expf(-s));
+            pq = prob * (1.f - prob);
+            g = (prob - t) * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f)) * pq;
+        } else {
+            prob = 1.f / (1.f + expf(-s));
+            pq = prob * (1.f - prob);
+            g = (prob - t) / fmaxf(pq, 1e-12f) * pq;
+        }
         if (threadIdx.x == 0) {
+            const float lp = fmaxf(logf(prob), -100.f);
+            const float lq = fmaxf(logf(1.f - prob), -100.f);
             local += -(t * lp + (1.f - t) * lq);
             dl[p] = g;
         }
-        if (mask)  // iterations 4 w .. 4 w + 3 = nibbles 4 (w % 2) .. + 3 of word w / 2: its low or high half
-            mask16[(((long)p * NW + (wave >> 1)) * 64 + lane) * 2 + (wave & 1)] = (uint16_t)bits16;
-        if (dw2_partial) {
+        // iterations 4 w .. 4 w + 3 = nibbles 4 (w % 2) .. + 3 of word w / 2: its low or high half.  Waves 0 and 2 store
+        // the WORD (their half and, from LDS, their odd neighbour's): as 2-byte stores of alternate halves from two
+        // waves they were byte-masked writes that L2 merges by read-modify-write (9.07 -> 8.4 ms at cfg 5).  (The whole
+        // pair's 512 bytes as 32 x 16-byte write-through stores from wave 0 -- so that the mask does not displace
+        // the graph's table rows in the XCD's L2 -- was measured too: 8.95 ms.)
+        if (mask && !(PAIR_ABL & 4) && !(wave & 1)) {
+            const uint32_t hi = (PAIR_ABL & 2) ? 0u : mb[((par * 2 + (wave >> 1)) * 64 + lane) * 2 + 1];
+            mask[((long)p * NW + (wave >> 1)) * 64 + lane] = bits16 | (hi << 16);
+        }
+        if (dw2_partial && !(PAIR_ABL & 8)) {
 #pragma unroll
-            for (int i = 0; i < NITW * 4; ++i) aw[i] += g * rv[i];
+            for (int i = 0; i < NITW * 2; ++i) aw[i] += pf2{g, g} * rv[i];
         }
         p = pn;
     }
@@ -318,7 +419,7 @@ __global__ __launch_bounds__(256) void pair_fwd_split_kernel(const float* __rest
         for (int ii = 0; ii < NITW; ++ii) {
             const int c = lane * 4 + 256 * (wave * NITW + ii);
             if (c < HEp) {
-                sh[c + 0] = aw[4 * ii + 0]; sh[c + 1] = aw[4 * ii + 1]; sh[c + 2] = aw[4 * ii + 2]; sh[c + 3] = aw[4 * ii + 3];
+                sh[c + 0] = aw[2 * ii].x; sh[c + 1] = aw[2 * ii].y; sh[c + 2] = aw[2 * ii + 1].x; sh[c + 3] = aw[2 * ii + 1].y;
             }
         }
         __syncthreads();
@@ -692,23 +793,35 @@ namespace dvae {
 int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a, const int32_t* pair_h,
                  const int32_t* pair_c, const uint8_t* pair_t, const float* b1, const float* w2, const float* b2, float* dl,
                  float* loss_sum, uint32_t* mask, float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp,
-                 float* sums, unsigned tickets, float beta, float* out3, void* stream, int group) {
+                 float* sums, unsigned tickets, float beta, float* out3, void* stream, int group, int tables_bf16) {
     DVAE_REQUIRE(ea && eb && pair_a && pair_h && pair_t && b1 && w2 && b2 && dl && loss_sum, "pair_bce_fwd: null pointer");
     DVAE_REQUIRE((ec == nullptr) == (pair_c == nullptr), "pair_bce_fwd: ec and pair_c go together");
     DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0 && n_blocks > 0, "pair_bce_fwd: HEp must be a multiple of 4, n_blocks > 0");
     const int nit = pair_nit(HEp);
     DVAE_REQUIRE(nit > 0, "pair_bce_fwd: HEp %d exceeds 4096", HEp);
     if (n_pairs == 0 && !dw2_partial && !sums) return DVAE_OK;
-    const size_t shm = ((size_t)HEp + 8) * sizeof(float);
+    const size_t shm = ((size_t)HEp + 8) * sizeof(float) + 2 * 4 * 64 * sizeof(uint16_t);  // (+ the split kernel's mask halves)
     dim3 grid(n_blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
     static const int knob_split = getenv("DVAE_PAIR_SPLIT") ? atoi(getenv("DVAE_PAIR_SPLIT")) : 1;  // 0: one wave per pair at every width
     if (nit == 16 && knob_split) {  // wide tables: four waves per pair
-        hipLaunchKernelGGL((pair_fwd_split_kernel<4>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2,
-                           b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3, group);
+#define DVAE_PAIR_SPLIT(TH_, FULL_)                                                                                    \
+    hipLaunchKernelGGL((pair_fwd_split_kernel<4, TH_, FULL_>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, \
+                       b1, w2, b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3, group)
+        const bool full = HEp == 4096;
+        if (tables_bf16) {
+            DVAE_REQUIRE(!ec, "pair_bce_fwd: bf16-stored tables are not built for the three-table (DVAE_BN) form");
+            if (full) DVAE_PAIR_SPLIT(true, true);
+            else DVAE_PAIR_SPLIT(true, false);
+        } else {
+            if (full) DVAE_PAIR_SPLIT(false, true);
+            else DVAE_PAIR_SPLIT(false, false);
+        }
+#undef DVAE_PAIR_SPLIT
         DVAE_LAUNCH_CHECK();
         return DVAE_OK;
     }
+    DVAE_REQUIRE(!tables_bf16, "pair_bce_fwd: bf16-stored tables need the wide-table kernel (2048 < HEp <= 4096)");
 #define DVAE_PAIR_FWD(N)                                                                                              \
     hipLaunchKernelGGL((pair_fwd_kernel<N>), grid, block, shm, s, ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, \
                        b2, dl, loss_sum, mask, dw2_partial, n_pairs, HEp, sums, tickets, beta, out3, group)
@@ -730,7 +843,7 @@ extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* 
                                  const float* w2, const float* b2, float* dl, float* loss_sum, uint32_t* mask,
                                  float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp, void* stream) {
     return dvae::pair_bce_fwd(ea, eb, ec, pair_a, pair_h, pair_c, pair_t, b1, w2, b2, dl, loss_sum, mask, dw2_partial, n_blocks,
-                              n_pairs, HEp, nullptr, 0u, 0.f, nullptr, stream, 0);
+                              n_pairs, HEp, nullptr, 0u, 0.f, nullptr, stream, 0, 0);
 }
 
 extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,

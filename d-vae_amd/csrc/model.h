@@ -123,7 +123,7 @@ int vertex_ce_final(const float* logits, int ld, const int* ce_off, const int* c
 int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_t* pair_a, const int32_t* pair_h,
                  const int32_t* pair_c, const uint8_t* pair_t, const float* b1, const float* w2, const float* b2, float* dl,
                  float* loss_sum, uint32_t* mask, float* dw2_partial, int32_t n_blocks, int32_t n_pairs, int32_t HEp,
-                 float* sums, unsigned tickets, float beta, float* out3, void* stream, int group = 0);
+                 float* sums, unsigned tickets, float beta, float* out3, void* stream, int group = 0, int tables_bf16 = 0);
 int loss_bwd_init(const float* g3, float beta, float* gs, const float* dlogits, float* dlogits_s, long n_logits,
                   const int* ca_row, int CA, float* dea, int NA, const int* ch_row, int CH, float* deb, int NB, int HEp,
                   hipStream_t s);

@@ -80,11 +80,12 @@ static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s, int max_split
 }
 
 // Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
+// y_bf16 (bf16 mode only): Y is stored as bf16 (Y then points at bf16 words, ldy counts bf16 elements)
 static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
-                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s) {
+                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s, int y_bf16 = 0) {
     dvae_gemm_desc g = {};
     g.A = X; g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
-    g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc; g.c_bf16 = y_bf16;
     return run_gemm(g, s);
 }
 // dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)

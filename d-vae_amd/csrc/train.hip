@@ -298,6 +298,13 @@ struct DecWs {
     int dw2_blocks;
     size_t total;
 };
+// bf16 mode, wide edge-predictor tables (2048 < HEp <= 4096: the four-waves-per-pair kernels), DVAE: EA / EB stored as bf16
+// (DVAE_TABLES_BF16=0: fp32 as in round 2)
+static bool edge_tables_bf16(const Dims& d) {
+    static const int knob = [] { const char* v = getenv("DVAE_TABLES_BF16"); return v ? atoi(v) : 1; }();
+    static const int knob_split = [] { const char* v = getenv("DVAE_PAIR_SPLIT"); return v ? atoi(v) : 1; }();
+    return knob && knob_split && d.bf16 && !d.bn && d.HEp > 2048 && d.HEp <= 4096 && d.HEp % 8 == 0;
+}
 static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     DecWs w;
     Bump b{base, 0};
@@ -325,7 +332,8 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dea = b.take((size_t)(c.NA + 1) * HEp);
     w.deb = b.take((size_t)(c.NB + 1) * HEp);
     w.dec = d.bn ? b.take((size_t)c.B * HEp) : nullptr;
-    w.dw2_blocks = 1024;
+    // (the pair forward's workgroups: four per CU; five where its bf16-table form, 90 registers, runs)
+    w.dw2_blocks = edge_tables_bf16(d) ? 1280 : 1024;
     w.dw2p = b.take((size_t)w.dw2_blocks * HEp);
     w.dst = b.take(NST * Hp);
     w.dv1 = b.take((size_t)c.R * d.HVp);
@@ -919,6 +927,14 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     const float* bhn = pw + L.bhn[2];
 
     const bool by_level = loss_by_level(d, *c);
+    // bf16 mode, wide tables (cfg 5: HEp = 4096): EA / EB are STORED as bf16 by the products that make them (the pair
+    // kernel is their only reader; the backward passes use its ReLU masks).  Same allocation, rows HEp bf16 words apart.
+    const bool th = edge_tables_bf16(d);
+    uint16_t* ea_h = reinterpret_cast<uint16_t*>(w.ea);
+    uint16_t* eb_h = reinterpret_cast<uint16_t*>(w.eb);
+    float* ea_zero = th ? reinterpret_cast<float*>(ea_h + (size_t)c->NA * HEp) : w.ea + (size_t)c->NA * HEp;
+    float* eb_zero = th ? reinterpret_cast<float*>(eb_h + (size_t)c->NB * HEp) : w.eb + (size_t)c->NB * HEp;
+    const int zero_floats = th ? HEp / 2 : HEp;  // the all-zero row of each table
     SideGuard side_guard(s);
     Side*& side = side_guard.sd;
     if (by_level) DVAE_TRY(side_acquire(side_guard));
@@ -927,12 +943,12 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // 0.4 % slower on the cfg-2 step than the launches it saved), which still zeroes the two rows
     const bool one_init = (long)B * d.NZp <= 8192;
     if (one_init) {
-        DVAE_TRY(loss_fwd_init(mu, logvar, eps, eps_scale, training, w.z, w.sums, w.ea + (size_t)c->NA * HEp,
-                               w.eb + (size_t)c->NB * HEp, HEp, B, d.nz, d.NZp, s));
+        DVAE_TRY(loss_fwd_init(mu, logvar, eps, eps_scale, training, w.z, w.sums, ea_zero, eb_zero, zero_floats, B, d.nz,
+                               d.NZp, s));
     } else {
         DVAE_HIP(hipMemsetAsync(w.sums, 0, 8 * sizeof(float), s));
-        DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s,
-                                 w.ea + (size_t)c->NA * HEp, w.eb + (size_t)c->NB * HEp, HEp));
+        DVAE_TRY(reparam_kld_fwd(mu, logvar, eps, eps_scale, training, w.z, w.sums + 2, B, d.nz, d.NZp, s, ea_zero, eb_zero,
+                                 zero_floats));
     }
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
@@ -982,7 +998,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 // fill the CUs the latency-bound chain leaves idle (as the second encoder direction does).
                 hipStream_t s2 = side->stream;
                 DVAE_TRY(fork_side(side_guard));
-                DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.w1a, Hp, nullptr, w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2));
+                DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.w1a, Hp, nullptr,
+                                 th ? reinterpret_cast<float*>(ea_h + r0 * HEp) : w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2, th));
                 DVAE_TRY(dvae_gather_sum_f32(w.vs + r0 * Hp, Hp, w.st, Hp, bv.vs_off + r0, bv.vs_idx, B, Hp, 0, s2));
                 DVAE_TRY(lin_fwd(w.vs + r0 * Hp, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1 + r0 * d.HVp, d.HVp, B, d.HVp,
                                  Hp, 1, 0, s2));
@@ -1020,13 +1037,15 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // (level-major batches: running this tail on the side stream under the products below was measured: 0.4 % slower
     // step -- the Tp-wide product and the CE kernel then share the CUs with the edge predictor's large product)
     // edge predictor: first layer split over its inputs
-    if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s));
-    DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s));
+    if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s, th));
+    // (bf16 tables: b1 goes into EB here -- and into its no-input row -- instead of into every pair's sum)
+    DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, th ? pw + L.be1 : nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s, th));
+    if (th) DVAE_TRY(dvae_f32_to_bf16(pw + L.be1, eb_h + (size_t)c->NB * HEp, HEp, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));
     if (by_level) DVAE_TRY(join_side(side_guard));
     DVAE_TRY(pair_bce_fwd(w.ea, w.eb, w.ec, bv.pair_a, bv.pair_h, d.bn ? bv.pair_c : nullptr, bv.pair_t, pw + L.be1,
                           pw + L.we2, pw + L.be2, w.dl, w.sums + 0, w.mask, w.dw2p, nblk, c->NP, HEp, w.sums, tickets,
-                          beta, out3, s, (pair_group_knob() && c->B >= w.dw2_blocks / 2) ? c->NP / c->B : 0));
+                          beta, out3, s, (pair_group_knob() && c->B >= w.dw2_blocks / 2) ? c->NP / c->B : 0, th));
     // (whole graphs per workgroup only when there are graphs enough to fill the grid: at batch 32 that mapping left 32
     // workgroups walking 28 pairs each, 63 us instead of ~12)
     // vertex-type predictor

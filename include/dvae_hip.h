@@ -66,6 +66,10 @@ typedef struct dvae_gemm_desc {
                                point at uint16 bf16 words, lda / ldb count bf16 elements; 16-byte aligned rows,
                                K % 8 == 0).  Half the operand bytes and no conversion in the K loop: see
                                gemm_bf16_nn.hip.  dvae_gemm_f32 refuses them. */
+    int32_t c_bf16;         /* dvae_gemm_bf16 only, products of two K-contiguous operands only: C is STORED as bf16 (C then
+                               points at uint16 bf16 words, ldc counts bf16 elements; 8-byte aligned rows, N % 4 == 0;
+                               bias and c_rows allowed; no activation, accumulate or relu_mask).  For outputs that only
+                               feed bf16-tolerant consumers (the edge predictor's tables in bf16 mode). */
 } dvae_gemm_desc;
 int dvae_gemm_f32(const dvae_gemm_desc* d, void* stream);
 /* The same product on the kernel for FEW ROWS (csrc/gemm_skinny.hip): 16-row x (16 nt)-column tiles whose eight waves
