@@ -76,15 +76,19 @@ static inline int run_gemm(const dvae_gemm_desc& g, hipStream_t s, int max_split
     }
     dvae_gemm_desc h = g;
     use_bf16_weight_copy(h);
+    if (h.a_bf16 && !h.b_bf16) return set_err(DVAE_ERR_ARG, "run_gemm: a bf16 activation shadow needs the bf16 weight copy");
     return gemm_bf16(h, s);
 }
 
 // Y[M x N] (+)= act(X[M x K] W[N x K]^T + bias)       (forward of a Linear)
 // y_bf16 (bf16 mode only): Y is stored as bf16 (Y then points at bf16 words, ldy counts bf16 elements)
+// x_h (bf16 mode only, nullable): the bf16 shadow of X (same row pitch in elements): the product reads it instead
 static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, int ldw, const float* bias, float* Y,
-                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s, int y_bf16 = 0) {
+                   int ldy, int M, int N, int K, int act, int acc, hipStream_t s, int y_bf16 = 0,
+                   const uint16_t* x_h = nullptr) {
     dvae_gemm_desc g = {};
-    g.A = X; g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
+    g.A = x_h ? reinterpret_cast<const float*>(x_h) : X; g.a_bf16 = x_h ? 1 : 0;
+    g.lda = ldx; g.a_rows = xrows; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = acc; g.c_bf16 = y_bf16;
     return run_gemm(g, s);
 }

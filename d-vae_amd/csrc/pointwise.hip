@@ -10,11 +10,19 @@ namespace dvae {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// bf16 SHADOW of an activation row (round 3, bf16 mode): the kernels that produce a state / predecessor sum that a
+// bf16 product reads next also store it rounded to bf16 (8 bytes per lane beside the 16 of the fp32 row, which the
+// backward pass and the gathers keep reading): the product then pulls half the A bytes through L2 and converts nothing.
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4h(uint16_t* p, float4 v) {
+    const pbf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, b);
+}
 
 // ---------------------------------------------------------------------------
 __global__ void gather_sum_kernel(float* __restrict__ out, int ld_out, const float* __restrict__ src, int ld_src,
                                   const int* __restrict__ off, const int* __restrict__ idx, int rows, int w4,
-                                  int accumulate) {
+                                  int accumulate, uint16_t* __restrict__ out_h) {
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / w4), c = (int)(i % w4) * 4;
@@ -30,6 +38,7 @@ __global__ void gather_sum_kernel(float* __restrict__ out, int ld_out, const flo
         }
         if (k < k1) acc = add4(acc, ld4(src + (long)idx[k] * ld_src + c));
         st4(out + (long)r * ld_out + c, acc);
+        if (out_h) st4h(out_h + (long)r * ld_out + c, acc);
     }
 }
 
@@ -49,7 +58,8 @@ __global__ void scatter_rows_add_kernel(float* __restrict__ dst, int ld_dst, con
 // ---------------------------------------------------------------------------
 __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__ gi_tab, const int* __restrict__ types,
                                const float* __restrict__ bhn, const float* __restrict__ hprev, int ld_hprev,
-                               float* __restrict__ hout, int ld_hout, float* __restrict__ ghn_out, int rows, int Hp) {
+                               float* __restrict__ hout, int ld_hout, float* __restrict__ ghn_out, int rows, int Hp,
+                               uint16_t* __restrict__ hout_h) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -77,6 +87,7 @@ __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__
         st4(g + 2 * Hp + c, N);
         st4(ghn_out + (long)r * Hp + c, GN);
         st4(hout + (long)r * ld_hout + c, Hn);
+        if (hout_h) st4h(hout_h + (long)r * ld_hout + c, Hn);
     }
 }
 
@@ -86,7 +97,7 @@ __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__
 __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __restrict__ gi_tab,
                                      const int* __restrict__ types, const float* __restrict__ bhn,
                                      float* __restrict__ agg_zero, float* __restrict__ hout, float* __restrict__ ghn_out,
-                                     int rows, int Hp) {
+                                     int rows, int Hp, uint16_t* __restrict__ hout_h) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -112,6 +123,7 @@ __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __r
         st4(g + 2 * Hp + c, N);
         st4(ghn_out + (long)r * Hp + c, bn);
         st4(hout + (long)r * Hp + c, Hn);
+        if (hout_h) st4h(hout_h + (long)r * Hp + c, Hn);
         st4(agg_zero + (long)r * Hp + c, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
@@ -198,7 +210,7 @@ __global__ void gated_bwd_kernel(const float* __restrict__ dmsg, int ld_dmsg, co
 __global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __restrict__ gv, float* __restrict__ msg,
                                         int ld_msg, int cur_row0, float* __restrict__ next_agg, int ld_agg,
                                         const int* __restrict__ next_off, const int* __restrict__ idx, int rows,
-                                        int Hp) {
+                                        int Hp, uint16_t* __restrict__ next_agg_h) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -219,6 +231,7 @@ __global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __r
                 acc = add4(acc, s == cur_row0 + r ? own : ld4(msg + (long)s * ld_msg + c));
             }
             st4(next_agg + (long)r * ld_agg + c, acc);
+            if (next_agg_h) st4h(next_agg_h + (long)r * ld_agg + c, acc);
         }
     }
 }
@@ -371,16 +384,23 @@ static inline int ew_grid(long total) {
 
 using namespace dvae;
 
-extern "C" int dvae_gather_sum_f32(float* out, int32_t ld_out, const float* src, int32_t ld_src, const int32_t* off,
-                                   const int32_t* idx, int32_t rows, int32_t width, int32_t accumulate, void* stream) {
+namespace dvae {
+// out_h (nullable): bf16 shadow of `out`, same row pitch in elements
+int gather_sum_h(float* out, int ld_out, const float* src, int ld_src, const int* off, const int* idx, int rows, int width,
+                 int accumulate, uint16_t* out_h, hipStream_t s) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(out && src && off, "gather_sum: null pointer");
     DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_out % 4 == 0 && ld_src % 4 == 0, "gather_sum: width/ld must be multiples of 4");
     long total = (long)rows * (width / 4);
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, out, ld_out, src,
-                       ld_src, off, idx, rows, width / 4, accumulate);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, s, out, ld_out, src, ld_src, off, idx, rows,
+                       width / 4, accumulate, out_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+extern "C" int dvae_gather_sum_f32(float* out, int32_t ld_out, const float* src, int32_t ld_src, const int32_t* off,
+                                   const int32_t* idx, int32_t rows, int32_t width, int32_t accumulate, void* stream) {
+    return dvae::gather_sum_h(out, ld_out, src, ld_src, off, idx, rows, width, accumulate, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dvae_scatter_rows_add_f32(float* dst, int32_t ld_dst, const float* src, int32_t ld_src,
@@ -396,26 +416,34 @@ extern "C" int dvae_scatter_rows_add_f32(float* dst, int32_t ld_dst, const float
     return DVAE_OK;
 }
 
-extern "C" int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int32_t* types, const float* bhn,
-                                      const float* hprev, int32_t ld_hprev, float* hout, int32_t ld_hout,
-                                      float* ghn_out, int32_t rows, int32_t Hp, void* stream) {
+namespace dvae {
+// hout_h (nullable): bf16 shadow of the new states, row pitch ld_hout elements
+int gru_pointwise_fwd_h(float* gh, const float* gi_tab, const int* types, const float* bhn, const float* hprev, int ld_hprev,
+                        float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(gh && gi_tab && types && bhn && hout && ghn_out, "gru_pointwise_fwd: null pointer");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_hout % 4 == 0 && (!hprev || ld_hprev % 4 == 0), "gru_pointwise_fwd: bad Hp/ld");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gh, gi_tab, types, bhn,
-                       hprev, ld_hprev, hout, ld_hout, ghn_out, rows, Hp);
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gh, gi_tab, types, bhn, hprev, ld_hprev, hout,
+                       ld_hout, ghn_out, rows, Hp, hout_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+extern "C" int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int32_t* types, const float* bhn,
+                                      const float* hprev, int32_t ld_hprev, float* hout, int32_t ld_hout,
+                                      float* ghn_out, int32_t rows, int32_t Hp, void* stream) {
+    return dvae::gru_pointwise_fwd_h(gh, gi_tab, types, bhn, hprev, ld_hprev, hout, ld_hout, ghn_out, rows, Hp, nullptr,
+                                     (hipStream_t)stream);
 }
 
 namespace dvae {
 int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
-                    float* ghn_out, int rows, int Hp, hipStream_t s) {
+                    float* ghn_out, int rows, int Hp, hipStream_t s, uint16_t* hout_h) {
     if (rows == 0) return DVAE_OK;
     long total = (long)rows * (Hp / 4);
     hipLaunchKernelGGL(gru_fwd_first_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gates, gi_tab, types, bhn, agg_zero,
-                       hout, ghn_out, rows, Hp);
+                       hout, ghn_out, rows, Hp, hout_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -458,19 +486,27 @@ extern "C" int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, cons
     return DVAE_OK;
 }
 
-extern "C" int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg, int32_t ld_msg, int32_t cur_row0,
-                                     float* next_agg, int32_t ld_agg, const int32_t* next_off, const int32_t* idx,
-                                     int32_t rows, int32_t Hp, void* stream) {
+namespace dvae {
+// next_agg_h (nullable): bf16 shadow of the next level's predecessor sums, row pitch ld_agg elements
+int gated_fwd_gather_h(float* gm, const float* gv_row, float* msg, int ld_msg, int cur_row0, float* next_agg, int ld_agg,
+                       const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(gm && gv_row && msg, "gated_fwd_gather: null pointer");
     DVAE_REQUIRE(!next_agg || (next_off && idx), "gated_fwd_gather: the next level's CSR lists are missing");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_msg % 4 == 0 && (!next_agg || ld_agg % 4 == 0) && cur_row0 >= 0,
                  "gated_fwd_gather: bad size");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gated_fwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gm, gv_row, msg,
-                       ld_msg, cur_row0, next_agg, ld_agg, next_off, idx, rows, Hp);
+    hipLaunchKernelGGL(gated_fwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gm, gv_row, msg, ld_msg, cur_row0,
+                       next_agg, ld_agg, next_off, idx, rows, Hp, next_agg ? next_agg_h : nullptr);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+extern "C" int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg, int32_t ld_msg, int32_t cur_row0,
+                                     float* next_agg, int32_t ld_agg, const int32_t* next_off, const int32_t* idx,
+                                     int32_t rows, int32_t Hp, void* stream) {
+    return dvae::gated_fwd_gather_h(gm, gv_row, msg, ld_msg, cur_row0, next_agg, ld_agg, next_off, idx, rows, Hp, nullptr,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx,

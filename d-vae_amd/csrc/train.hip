@@ -251,8 +251,16 @@ struct EncWs {
     float *dhs[2], *dgm[2], *dgh[2], *dgin[2], *dagg[2], *cnt[2];
     float *d12, *dhgu, *dhg;
     float* sync;  // counters of the persistent chain kernel (chain.hip: enc_chain_fwd), used as unsigned storage
+    uint16_t *hs_h[2], *agg_h[2];  // bf16 shadows of hs / agg (act_shadows(): what the forward products read), or null
     size_t total;
 };
+// bf16 mode, levels large enough for the bf16 product kernels (above the exact-fp32 small-level kernels), DVAE: the
+// forward chains' states and predecessor sums get bf16 shadows (pointwise.hip: st4h) that the products read
+// (DVAE_ACT_BF16=0: fp32 activations converted on their way into LDS, as in round 2; =2: at every batch size -- tests)
+static bool act_shadows(const Dims& d, int B) {
+    static const int knob = [] { const char* v = getenv("DVAE_ACT_BF16"); return v ? atoi(v) : 1; }();
+    return knob && d.bf16 && !d.bn && (B > 256 || knob == 2) && d.Hp % 8 == 0;
+}
 static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
     EncWs w;
     Bump b{base, 0};
@@ -284,6 +292,11 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dhgu = b.take((size_t)c.B * Hp);
     w.dhg = b.take((size_t)c.B * 2 * Hp);
     w.sync = b.take(ENC_CHAIN_SYNC_WORDS);  // (>= 2 TINY_CHAIN_SYNC_WORDS: slot 0 forward, slot 1 backward launch)
+    for (int k = 0; k < 2; ++k) {
+        const bool on = k < dirs && act_shadows(d, c.B);
+        w.hs_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * Hp / 2)) : nullptr;
+        w.agg_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * Hp / 2)) : nullptr;
+    }
     w.total = b.off;
     return w;
 }
@@ -295,6 +308,7 @@ struct DecWs {
     // backward
     float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dgm, *dh0c, *dz, *gs;
     float* sync;  // counters of the persistent small-batch chain (chain_persist.hip), used as unsigned storage
+    uint16_t *st_h, *agg_h;  // bf16 shadows of st / agg (act_shadows()), or null
     int dw2_blocks;
     size_t total;
 };
@@ -346,6 +360,9 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     w.dz = b.take((size_t)c.B * d.NZp);
     w.gs = b.take(8);
     w.sync = b.take(2 * TINY_CHAIN_SYNC_WORDS);  // slot 0: the forward launch, slot 1: the backward launch
+    const bool sh = act_shadows(d, c.B);
+    w.st_h = sh ? reinterpret_cast<uint16_t*>(b.take(NST * Hp / 2)) : nullptr;
+    w.agg_h = sh ? reinterpret_cast<uint16_t*>(b.take(NST * Hp / 2)) : nullptr;
     w.total = b.off;
     return w;
 }
@@ -572,18 +589,21 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         const long r0 = (long)v * B;
         float* agg = w.agg[k] + r0 * Hp;
         float* gates = w.gates[k] + r0 * 3 * Hp;
+        // bf16 shadows (act_shadows; unfused path only -- the fused level kernels read fp32): this level's rows
+        uint16_t* hs_h = (w.hs_h[k] && !fused) ? w.hs_h[k] + r0 * Hp : nullptr;
+        uint16_t* agg_h = (w.agg_h[k] && !fused) ? w.agg_h[k] + r0 * Hp : nullptr;
         if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0 (one launch; leaves agg = 0 for the backward)
             DVAE_TRY(gru_first_level(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, w.hs[k] + r0 * Hp,
-                                     w.ghn[k] + r0 * Hp, B, Hp, s));
+                                     w.ghn[k] + r0 * Hp, B, Hp, s, hs_h));
         } else if (!fused) {
-            DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
+            DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s, 0, agg_h));
         }
         if (fused && step > 0)  // hidden product + GRU tail in one launch (chain.hip)
             DVAE_TRY(dvae_gru_level_fwd(agg, Hp, pw + L.whh[k], pw + L.gi[k], bv.types + r0, pw + L.bhn[k], gates,
                                         w.ghn[k] + r0 * Hp, w.hs[k] + r0 * Hp, Hp, B, Hp, s));
         else if (step > 0)
-            DVAE_TRY(dvae_gru_pointwise_fwd(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp,
-                                            w.hs[k] + r0 * Hp, Hp, w.ghn[k] + r0 * Hp, B, Hp, s));
+            DVAE_TRY(gru_pointwise_fwd_h(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp, w.hs[k] + r0 * Hp, Hp,
+                                         w.ghn[k] + r0 * Hp, B, Hp, hs_h, s));
         if (step < n - 1) {
             const long r1 = (long)(k == 0 ? v + 1 : v - 1) * B;
             float* gm = w.gm[k] + r0 * 2 * Hp;
@@ -591,9 +611,9 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
                 DVAE_TRY(dvae_gated_level_fwd(w.hs[k] + r0 * Hp, Hp, pw + L.wgm[k], pw + L.gv[k] + (size_t)v * 2 * Hp, gm,
                                               w.msg[k], Hp, (int)r0, w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
             } else {
-                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
-                DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0,
-                                               w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
+                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s, 0, hs_h));
+                DVAE_TRY(gated_fwd_gather_h(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0, w.agg[k] + r1 * Hp, Hp,
+                                            off + r1, idx, B, Hp, w.agg_h[k] ? w.agg_h[k] + r1 * Hp : nullptr, s));
             }
         }
         return DVAE_OK;
@@ -968,8 +988,11 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
         DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
     } else {
         DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
-        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, s));
+        DVAE_TRY(gru_pointwise_fwd_h(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, w.st_h, s));
     }
+    // bf16 shadows of the states and predecessor sums (act_shadows; the unfused path writes and reads them)
+    uint16_t* const st_h = (!tiny && !fused) ? w.st_h : nullptr;
+    uint16_t* const agg_h = (!tiny && !fused) ? w.agg_h : nullptr;
     if (d.bn) {
         // no recurrence: messages depend on predecessor types only (models.py:1044-1062)
         const long r0 = B;
@@ -988,9 +1011,10 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 DVAE_TRY(dvae_gru_level_fwd(w.agg + r0 * Hp, Hp, whh, gi, bv.types + r0, bhn, w.gates + r0 * 3 * Hp,
                                             w.ghn + r0 * Hp, w.st + r0 * Hp, Hp, B, Hp, s));
             } else if (v > 0) {
-                DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
-                DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
-                                                w.st + r0 * Hp, Hp, w.ghn + r0 * Hp, B, Hp, s));
+                DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s,
+                                 0, agg_h ? agg_h + r0 * Hp : nullptr));
+                DVAE_TRY(gru_pointwise_fwd_h(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp, w.st + r0 * Hp, Hp,
+                                             w.ghn + r0 * Hp, B, Hp, st_h ? st_h + r0 * Hp : nullptr, s));
             }
             if (by_level && v < n - 1) {
                 // The state of level v is final: its rows of the EA table and its vertex-type rows
@@ -999,7 +1023,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 hipStream_t s2 = side->stream;
                 DVAE_TRY(fork_side(side_guard));
                 DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.w1a, Hp, nullptr,
-                                 th ? reinterpret_cast<float*>(ea_h + r0 * HEp) : w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2, th));
+                                 th ? reinterpret_cast<float*>(ea_h + r0 * HEp) : w.ea + r0 * HEp, HEp, B, HEp, Hp, 0, 0, s2, th,
+                                 st_h ? st_h + r0 * Hp : nullptr));
                 DVAE_TRY(dvae_gather_sum_f32(w.vs + r0 * Hp, Hp, w.st, Hp, bv.vs_off + r0, bv.vs_idx, B, Hp, 0, s2));
                 DVAE_TRY(lin_fwd(w.vs + r0 * Hp, Hp, nullptr, pw + L.wv1, Hp, pw + L.bv1, w.v1 + r0 * d.HVp, d.HVp, B, d.HVp,
                                  Hp, 1, 0, s2));
@@ -1011,19 +1036,22 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                                                   w.msg, Hp, (int)r0, w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B,
                                                   bv.pred_idx, B, Hp, s));
                 } else {
-                    DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s));
+                    DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s, 0,
+                                     st_h ? st_h + r0 * Hp : nullptr));
                     // pointwise tail + predecessor sum of vertex v + 1
-                    DVAE_TRY(dvae_gated_fwd_gather(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0,
-                                                   w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp, s));
+                    DVAE_TRY(gated_fwd_gather_h(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0, w.agg + (r0 + B) * Hp,
+                                                Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp,
+                                                agg_h ? agg_h + (r0 + B) * Hp : nullptr, s));
                 }
             }
         }
         // partial states: non-recurrent, one batched pass
         const long p0 = nB;
-        DVAE_TRY(dvae_gather_sum_f32(w.agg + p0 * Hp, Hp, w.msg, Hp, bv.p_off, bv.p_idx, PT, Hp, 0, s));
-        DVAE_TRY(lin_fwd(w.agg + p0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + p0 * 3 * Hp, 3 * Hp, PT, 3 * Hp, Hp, 0, 0, s));
-        DVAE_TRY(dvae_gru_pointwise_fwd(w.gates + p0 * 3 * Hp, gi, bv.p_type, bhn, w.agg + p0 * Hp, Hp, w.st + p0 * Hp,
-                                        Hp, w.ghn + p0 * Hp, PT, Hp, s));
+        DVAE_TRY(gather_sum_h(w.agg + p0 * Hp, Hp, w.msg, Hp, bv.p_off, bv.p_idx, PT, Hp, 0, agg_h ? agg_h + p0 * Hp : nullptr, s));
+        DVAE_TRY(lin_fwd(w.agg + p0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + p0 * 3 * Hp, 3 * Hp, PT, 3 * Hp, Hp, 0, 0, s, 0,
+                         agg_h ? agg_h + p0 * Hp : nullptr));
+        DVAE_TRY(gru_pointwise_fwd_h(w.gates + p0 * 3 * Hp, gi, bv.p_type, bhn, w.agg + p0 * Hp, Hp, w.st + p0 * Hp, Hp,
+                                     w.ghn + p0 * Hp, PT, Hp, st_h ? st_h + p0 * Hp : nullptr, s));
     }
     // The loss terms meet through tickets (loss_kernels.hip: loss_ticket): the pair kernel's and the CE kernel's
     // workgroups each draw one, the last writes out3 -- so the vertex-type predictor's tail can run on the side stream.
@@ -1037,8 +1065,10 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     // (level-major batches: running this tail on the side stream under the products below was measured: 0.4 % slower
     // step -- the Tp-wide product and the CE kernel then share the CUs with the edge predictor's large product)
     // edge predictor: first layer split over its inputs
-    if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s, th));
+    if (!by_level) DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsA, pw + L.w1a, Hp, nullptr, w.ea, HEp, c->NA, HEp, Hp, 0, 0, s, th, st_h));
     // (bf16 tables: b1 goes into EB here -- and into its no-input row -- instead of into every pair's sum)
+    // (the row-GATHERED product keeps reading the fp32 states: on the bf16 shadow the gathering loader of
+    // gemm_bf16_nn_kernel -- per-row 64-bit addresses, 80 bytes of scratch -- ran 6.7 ms against 5.1)
     DVAE_TRY(lin_fwd(w.st, Hp, bv.rowsB, pw + L.w1b, Hp, th ? pw + L.be1 : nullptr, w.eb, HEp, c->NB, HEp, Hp, 0, 0, s, th));
     if (th) DVAE_TRY(dvae_f32_to_bf16(pw + L.be1, eb_h + (size_t)c->NB * HEp, HEp, s));
     if (d.bn) DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, pw + L.w1c, Hp, nullptr, w.ec, HEp, B, HEp, Hp, 0, 0, s));

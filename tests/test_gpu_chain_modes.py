@@ -44,6 +44,19 @@ def test_parity_with_fused_level_kernels_forced(extra):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_bf16_parity_with_activation_shadows_forced():
+    """bf16 mode above 256 graphs per batch: the forward chains' states and predecessor sums get bf16 shadows that the
+    products read (csrc/train.hip: act_shadows).  The parity batches are smaller: DVAE_ACT_BF16=2 forces the shadows at
+    every size, and the bf16-mode parity cases must hold with them."""
+    env = dict(os.environ, DVAE_ACT_BF16="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "cfg5_shape_bf16_mode_close_to_oracle or bf16_mode_close_to_oracle", "-p", "no:cacheprovider",
+                        "--timeout", "120", "--timeout-method", "thread"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 @pytest.mark.parametrize("rows", ["64", "128"])
 def test_bf16_parity_with_bf16_level_kernels_forced(rows):
     """(rows: the kernels' row tile, DVAE_CHAIN_BF16_ROWS: 64 = two workgroups per CU, the launch default; 128 = round 2's.)
