@@ -120,6 +120,10 @@ int gather_sum_h(float* out, int ld_out, const float* src, int ld_src, const int
                  int accumulate, uint16_t* out_h, hipStream_t s);
 int gru_pointwise_fwd_h(float* gh, const float* gi_tab, const int* types, const float* bhn, const float* hprev, int ld_hprev,
                         float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s);
+int gru_pointwise_bwd_h(const float* dh, int ld_dh, const float* gates, const float* ghn, const float* hprev, int ld_hprev,
+                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s);
+int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx, const float* dagg2, const int* off2,
+                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s);
 int gated_fwd_gather_h(float* gm, const float* gv_row, float* msg, int ld_msg, int cur_row0, float* next_agg, int ld_agg,
                        const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s);
 int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,

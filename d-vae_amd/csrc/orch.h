@@ -94,11 +94,26 @@ static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, in
 }
 // dX[M x K] (+)= dY[M x N] W[N x K]                    (input gradient of a Linear)
 // relu_out (nullable, laid out like dX): the layer's input was relu_out = ReLU(.), and dX is masked by relu_out > 0
+// dy_h (bf16 mode only, nullable): the bf16 shadow of dY (same row pitch in elements).  Used only when the product
+// will run on the transposed bf16 weight copy (two K-contiguous operands); otherwise the fp32 dY is read as before.
 static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
-                     int N, int K, int acc, hipStream_t s, const float* relu_out = nullptr) {
+                     int N, int K, int acc, hipStream_t s, const float* relu_out = nullptr, const uint16_t* dy_h = nullptr) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
     g.M = M; g.N = K; g.K = N; g.accumulate = acc; g.relu_mask = relu_out;
+    if (dy_h && tl_bf16) {
+        {  // small products stay exact fp32, as in run_gemm
+            const int rc = gemm_skinny(g, s, 0);
+            if (rc != 1) return rc;
+        }
+        dvae_gemm_desc h = g;
+        use_bf16_weight_copy(h);
+        if (h.b_bf16 && !h.b_kmajor) {  // the transposed copy serves it: A may be the shadow
+            h.A = reinterpret_cast<const float*>(dy_h);
+            h.a_bf16 = 1;
+            return gemm_bf16(h, s);
+        }
+    }
     return run_gemm(g, s);
 }
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)

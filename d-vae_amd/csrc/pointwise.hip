@@ -131,7 +131,7 @@ __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __r
 __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const float* __restrict__ gates,
                                const float* __restrict__ ghn, const float* __restrict__ hprev, int ld_hprev,
                                float* __restrict__ dgh, float* __restrict__ dgin, float* __restrict__ dhprev,
-                               int ld_dhprev, int rows, int Hp) {
+                               int ld_dhprev, int rows, int Hp, uint16_t* __restrict__ dgh_h) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -161,6 +161,12 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const fl
         st4(o + c, dR);
         st4(o + Hp + c, dZ);
         st4(o + 2 * Hp + c, dGN);
+        if (dgh_h) {  // bf16 shadow of d gh: the A operand of the level's data-gradient product
+            uint16_t* oh = dgh_h + (long)r * 3 * Hp;
+            st4h(oh + c, dR);
+            st4h(oh + Hp + c, dZ);
+            st4h(oh + 2 * Hp + c, dGN);
+        }
         st4(dgin + (long)r * Hp + c, dPN);
         if (dhprev) st4(dhprev + (long)r * ld_dhprev + c, dHP);
     }
@@ -241,7 +247,8 @@ __global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __r
 __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, const int* __restrict__ off,
                                         const int* __restrict__ idx, const float* __restrict__ dagg2,
                                         const int* __restrict__ off2, const int* __restrict__ idx2,
-                                        const float* __restrict__ gm, float* __restrict__ dgm, int rows, int Hp) {
+                                        const float* __restrict__ gm, float* __restrict__ dgm, int rows, int Hp,
+                                        uint16_t* __restrict__ dgm_h) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -258,6 +265,11 @@ __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, 
         float* o = dgm + (long)r * 2 * Hp;
         st4(o + c, dg);
         st4(o + Hp + c, dm);
+        if (dgm_h) {  // bf16 shadow of d gm: the A operand of the level's data-gradient product
+            uint16_t* oh = dgm_h + (long)r * 2 * Hp;
+            st4h(oh + c, dg);
+            st4h(oh + Hp + c, dm);
+        }
     }
 }
 
@@ -449,17 +461,25 @@ int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, con
 }
 }  // namespace dvae
 
-extern "C" int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const float* gates, const float* ghn,
-                                      const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,
-                                      int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream) {
+namespace dvae {
+// dgh_h (nullable): bf16 shadow of d gh, row pitch 3 Hp elements
+int gru_pointwise_bwd_h(const float* dh, int ld_dh, const float* gates, const float* ghn, const float* hprev, int ld_hprev,
+                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(dh && gates && ghn && dgh && dgin, "gru_pointwise_bwd: null pointer");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_dh % 4 == 0, "gru_pointwise_bwd: bad Hp/ld");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dh, ld_dh, gates, ghn,
-                       hprev, ld_hprev, dgh, dgin, dhprev, ld_dhprev, rows, Hp);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, s, dh, ld_dh, gates, ghn, hprev, ld_hprev, dgh,
+                       dgin, dhprev, ld_dhprev, rows, Hp, dgh_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+extern "C" int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const float* gates, const float* ghn,
+                                      const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,
+                                      int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream) {
+    return dvae::gru_pointwise_bwd_h(dh, ld_dh, gates, ghn, hprev, ld_hprev, dgh, dgin, dhprev, ld_dhprev, rows, Hp, nullptr,
+                                     (hipStream_t)stream);
 }
 
 extern "C" int dvae_gated_pointwise_fwd(float* gm, const float* gv, float* msg, int32_t ld_msg, int32_t rows,
@@ -509,18 +529,25 @@ extern "C" int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg,
                                     (hipStream_t)stream);
 }
 
-extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx,
-                                     const float* dagg2, const int32_t* off2, const int32_t* idx2, const float* gm,
-                                     float* dgm, int32_t rows, int32_t Hp, void* stream) {
+namespace dvae {
+// dgm_h (nullable): bf16 shadow of d gm, row pitch 2 Hp elements
+int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx, const float* dagg2, const int* off2,
+                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(dagg && off && idx && gm && dgm, "gated_bwd_gather: null pointer");
     DVAE_REQUIRE(!off2 || (dagg2 && idx2), "gated_bwd_gather: second list incomplete");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld % 4 == 0, "gated_bwd_gather: bad size");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gated_bwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dagg, ld, off,
-                       idx, dagg2, off2, idx2, gm, dgm, rows, Hp);
+    hipLaunchKernelGGL(gated_bwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, s, dagg, ld, off, idx, dagg2, off2, idx2,
+                       gm, dgm, rows, Hp, dgm_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
+}
+}  // namespace dvae
+extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx,
+                                     const float* dagg2, const int32_t* off2, const int32_t* idx2, const float* gm,
+                                     float* dgm, int32_t rows, int32_t Hp, void* stream) {
+    return dvae::gated_bwd_gather_h(dagg, ld, off, idx, dagg2, off2, idx2, gm, dgm, rows, Hp, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dvae_type_csr(const int32_t* types_a, int32_t na, const int32_t* types_b, int32_t nb, int32_t T,

@@ -252,6 +252,7 @@ struct EncWs {
     float *d12, *dhgu, *dhg;
     float* sync;  // counters of the persistent chain kernel (chain.hip: enc_chain_fwd), used as unsigned storage
     uint16_t *hs_h[2], *agg_h[2];  // bf16 shadows of hs / agg (act_shadows(): what the forward products read), or null
+    uint16_t *dgh_h[2], *dgm_h[2]; // ... of d gh / d gm (what the backward chains' data-gradient products read)
     size_t total;
 };
 // bf16 mode, levels large enough for the bf16 product kernels (above the exact-fp32 small-level kernels), DVAE: the
@@ -296,6 +297,8 @@ static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
         const bool on = k < dirs && act_shadows(d, c.B);
         w.hs_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * Hp / 2)) : nullptr;
         w.agg_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * Hp / 2)) : nullptr;
+        w.dgh_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * 3 * Hp / 2)) : nullptr;
+        w.dgm_h[k] = on ? reinterpret_cast<uint16_t*>(b.take(nB * 2 * Hp / 2)) : nullptr;
     }
     w.total = b.off;
     return w;
@@ -309,6 +312,7 @@ struct DecWs {
     float *dlogits_s, *dea, *deb, *dec, *dw2p, *dst, *dv1, *dvs, *dgh, *dgin, *dagg, *dgm, *dh0c, *dz, *gs;
     float* sync;  // counters of the persistent small-batch chain (chain_persist.hip), used as unsigned storage
     uint16_t *st_h, *agg_h;  // bf16 shadows of st / agg (act_shadows()), or null
+    uint16_t *dgh_h, *dgm_h; // ... of d gh / d gm
     int dw2_blocks;
     size_t total;
 };
@@ -363,6 +367,8 @@ static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     const bool sh = act_shadows(d, c.B);
     w.st_h = sh ? reinterpret_cast<uint16_t*>(b.take(NST * Hp / 2)) : nullptr;
     w.agg_h = sh ? reinterpret_cast<uint16_t*>(b.take(NST * Hp / 2)) : nullptr;
+    w.dgh_h = sh ? reinterpret_cast<uint16_t*>(b.take(NST * 3 * Hp / 2)) : nullptr;
+    w.dgm_h = (sh && !d.bn) ? reinterpret_cast<uint16_t*>(b.take(nB * 2 * Hp / 2)) : nullptr;
     w.total = b.off;
     return w;
 }
@@ -793,10 +799,14 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         const int v = k == 0 ? step : n - 1 - step;
         const long r0 = (long)v * B;
         float* dhs = w.dhs[k] + r0 * Hp;
+        // bf16 shadows of this level's d gm / d gh (act_shadows; unfused path)
+        uint16_t* dgm_h = (w.dgm_h[k] && !fused) ? w.dgm_h[k] + r0 * 2 * Hp : nullptr;
+        uint16_t* dgh_h = (w.dgh_h[k] && !fused) ? w.dgh_h[k] + r0 * 3 * Hp : nullptr;
         if (step < n - 1 && !fused) {
-            DVAE_TRY(dvae_gated_bwd_gather(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr,
-                                           w.gm[k] + r0 * 2 * Hp, w.dgm[k] + r0 * 2 * Hp, B, Hp, s));
-            DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+            DVAE_TRY(gated_bwd_gather_h(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr, w.gm[k] + r0 * 2 * Hp,
+                                        w.dgm[k] + r0 * 2 * Hp, B, Hp, dgm_h, s));
+            DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
+                               dgm_h));
         }
         // (fused: d gm of this level was written by the tail of the previous level's dgrad kernel, below)
         if (fused && step < n - 1)  // d h += d gm [Wg | Wm] and the GRU pointwise backward in one launch (chain.hip)
@@ -804,9 +814,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                                         w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
         else
-            DVAE_TRY(dvae_gru_pointwise_bwd(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp,
-                                            Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B,
-                                            Hp, s));
+            DVAE_TRY(gru_pointwise_bwd_h(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
+                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
+                                         step > 0 ? dgh_h : nullptr, s));
         if (step > 0 && fused) {
             // d agg += d gh W_hh, then -- same launch -- the gate/mapper pointwise backward of the level
             // processed next, whose d msg gathers d agg rows of this level (registers) and finished ones
@@ -819,7 +829,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
         } else if (step > 0)
             DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
-                               3 * Hp, Hp, 1, s));
+                               3 * Hp, Hp, 1, s, nullptr, dgh_h));
         if (wbl) {
             // final now: d gh of this level; d gm of the level processed next (fused: the tail above) or of this one
             if (dirs == 2) DVAE_TRY(aux_after(side_guard, s));
@@ -1172,9 +1182,14 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         EW(add_inplace_kernel, (long)B * Hp, w.dagg, w.dh0c, (long)B * Hp);
     } else {
         const long p0 = nB;
-        DVAE_TRY(dvae_gru_pointwise_bwd(w.dst + p0 * Hp, Hp, w.gates + p0 * 3 * Hp, w.ghn + p0 * Hp, w.agg + p0 * Hp, Hp,
-                                        w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp, s));
-        DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s));
+        // bf16 shadows of d gh / d gm (act_shadows; the unfused path writes and reads them)
+        uint16_t* const dgh_h = !fused ? w.dgh_h : nullptr;
+        uint16_t* const dgm_h = !fused ? w.dgm_h : nullptr;
+        DVAE_TRY(gru_pointwise_bwd_h(w.dst + p0 * Hp, Hp, w.gates + p0 * 3 * Hp, w.ghn + p0 * Hp, w.agg + p0 * Hp, Hp,
+                                     w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
+                                     dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, s));
+        DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s, nullptr,
+                           dgh_h ? dgh_h + p0 * 3 * Hp : nullptr));
         // (only the last vertex's rows of d gm are not written by the chain below)
         DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
         const bool tiny = fused && chain_tiny_persist(d, B);  // the reverse chain as one persistent launch
@@ -1206,10 +1221,11 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             float* dst = w.dst + r0 * Hp;
             if (v < n - 1 && !fused) {
                 // d msg = consumers' d agg (successor slots + partial rows), used in registers
-                DVAE_TRY(dvae_gated_bwd_gather(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp,
-                                               bv.pt_off + r0, bv.pt_idx, w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B,
-                                               Hp, s));
-                DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s));
+                DVAE_TRY(gated_bwd_gather_h(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp, bv.pt_off + r0, bv.pt_idx,
+                                            w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B, Hp,
+                                            dgm_h ? dgm_h + r0 * 2 * Hp : nullptr, s));
+                DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
+                                   dgm_h ? dgm_h + r0 * 2 * Hp : nullptr));
             }
             // (fused: d gm of vertex v was written by the tail of vertex v + 1's dgrad kernel, below)
             if (fused && v < n - 1)
@@ -1217,8 +1233,9 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                             w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp,
                                             w.dagg + r0 * Hp, Hp, B, Hp, s));
             else
-                DVAE_TRY(dvae_gru_pointwise_bwd(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp,
-                                                w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp, s));
+                DVAE_TRY(gru_pointwise_bwd_h(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp,
+                                             w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
+                                             dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, s));
             if (fused) {
                 dvae_level_desc da = {};
                 da.a = w.dgh + r0 * 3 * Hp; da.lda = 3 * Hp; da.K = 3 * Hp; da.w = whh;
@@ -1231,7 +1248,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                 }
                 DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
             } else
-                DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s));
+                DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s, nullptr,
+                                   dgh_h ? dgh_h + r0 * 3 * Hp : nullptr));
             if (wbl) {
                 // final now: d gh of vertex v, and d gm of vertex v - 1 (fused: the tail above) or v (unfused: this iteration)
                 const int vg = fused ? v - 1 : v;
