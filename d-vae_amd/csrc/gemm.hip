@@ -391,7 +391,7 @@ int gemm_check(const dvae_gemm_desc& d, int kmult) {
         // a row-gathered K-major operand is addressed as (row index * ldb + column) * 4 in 32 bits: the rows the
         // index list may name must all lie within the addressable span (chunking over K cannot rebase a gather)
         DVAE_REQUIRE(d.b_rows_bound > 0, "gemm: a row-gathered K-major B needs b_rows_bound (rows of the stored matrix)");
-        DVAE_REQUIRE((double)d.b_rows_bound * d.ldb * 4.0 < kmajor_span_limit(),
+        DVAE_REQUIRE((double)d.b_rows_bound * d.ldb * (d.b_bf16 ? 2.0 : 4.0) < kmajor_span_limit(),
                      "gemm: row-gathered K-major B spans %.0f bytes (b_rows_bound %d x ldb %d floats), limit %.0f",
                      (double)d.b_rows_bound * d.ldb * 4.0, d.b_rows_bound, d.ldb, kmajor_span_limit());
     }
@@ -404,8 +404,9 @@ int gemm_check(const dvae_gemm_desc& d, int kmult) {
 int gemm_k_chunk(const dvae_gemm_desc& d, int bk) {
     const double lim = kmajor_span_limit();
     double rowb = 0.0;
-    if (d.a_kmajor) rowb = d.lda * 4.0;
-    if (d.b_kmajor && !d.b_rows && d.ldb * 4.0 > rowb) rowb = d.ldb * 4.0;
+    const double ea = d.a_bf16 ? 2.0 : 4.0, eb = d.b_bf16 ? 2.0 : 4.0;  // bytes per stored element
+    if (d.a_kmajor) rowb = d.lda * ea;
+    if (d.b_kmajor && !d.b_rows && d.ldb * eb > rowb) rowb = d.ldb * eb;
     if (rowb == 0.0 || (double)d.K * rowb < lim) return d.K > 0 ? d.K : 1;
     DVAE_REQUIRE(d.act == 0 && !d.relu_mask, "gemm: a chunked contraction cannot apply an activation or a mask");
     const int kc = (int)(lim / rowb) / bk * bk;
@@ -417,12 +418,16 @@ bool gemm_next_chunk(const dvae_gemm_desc& d, int kc, int& k0, dvae_gemm_desc& s
     if (k0 >= d.K) return false;
     sub = d;
     sub.K = d.K - k0 < kc ? d.K - k0 : kc;
-    sub.A = d.a_kmajor ? d.A + (size_t)k0 * d.lda : d.A + k0;
+    // (bf16-stored operands: the pointers are typed float, the elements are 2 bytes)
+    auto adv = [](const float* p, size_t elems, int half) {
+        return half ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(p) + elems) : p + elems;
+    };
+    sub.A = adv(d.A, d.a_kmajor ? (size_t)k0 * d.lda : (size_t)k0, d.a_bf16);
     if (d.b_kmajor) {
         if (d.b_rows) sub.b_rows = d.b_rows + k0;
-        else sub.B = d.B + (size_t)k0 * d.ldb;
+        else sub.B = adv(d.B, (size_t)k0 * d.ldb, d.b_bf16);
     } else {
-        sub.B = d.B + k0;
+        sub.B = adv(d.B, (size_t)k0, d.b_bf16);
     }
     if (k0 > 0) { sub.accumulate = 1; sub.bias = nullptr; }
     // (a masked product is never chunked: gemm_k_chunk refuses an activation, and the mask is applied with it)

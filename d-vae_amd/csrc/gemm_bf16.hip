@@ -40,15 +40,19 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     return __builtin_bit_cast(uint2, b);
 }
 
-template <int ROWS, bool KMAJOR, bool KGATHER, int NT = 256>
+// HALF (K-major operands only): the operand is STORED as bf16 (a gradient table or an activation shadow written in
+// bf16 by its producer): a unit is 8 bytes of HBM instead of 16 and goes to LDS as loaded.
+template <int ROWS, bool KMAJOR, bool KGATHER, int NT = 256, bool HALF = false>
 struct TileLoaderH {
+    static_assert(!HALF || KMAJOR, "bf16-stored K-contiguous operands: gemm_bf16_nn.hip");
     static constexpr int UNITS = ROWS * 16 / NT;  // float4 units per thread: 2, 4 or 8
     static constexpr int KM_LD = KmLd<ROWS>::value;
     static constexpr int LDS_ELEMS = KMAJOR ? BKH * KM_LD : ROWS * KC_LDH;  // bf16 elements
     static constexpr int KROWS = NT / (ROWS / 4);                           // K-major: k rows covered by one unit round
     static_assert(UNITS == 2 || UNITS == 4 || UNITS == 8, "tile rows must be 32, 64 or 128 (256 threads), 256 (512 threads)");
 
-    float4 r[UNITS];
+    float4 r[HALF ? 1 : UNITS];
+    uint2 rh[HALF ? UNITS : 1];
     const float* rowp[UNITS];  // K-contig: start of the (gathered, clamped) row
     int nidx[UNITS];           // K-major gather: row indices of the NEXT tile to load
     const int* rows_;
@@ -99,9 +103,15 @@ struct TileLoaderH {
                 int kk = k0 + tid / (ROWS / 4) + KROWS * i;
                 bool ok = kk < kend && col_ != OOB;
                 unsigned ridx = KGATHER ? (unsigned)nidx[i] : (unsigned)kk;
-                unsigned off = ok ? (ridx * (unsigned)ld_ + col_) * 4u : OOB;
-                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, off, 0, 0);
-                r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                if constexpr (HALF) {
+                    unsigned off = ok ? (ridx * (unsigned)ld_ + col_) * 2u : OOB;
+                    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_, off, 0, 0);
+                    rh[i] = make_uint2(v.x, v.y);
+                } else {
+                    unsigned off = ok ? (ridx * (unsigned)ld_ + col_) * 4u : OOB;
+                    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, off, 0, 0);
+                    r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
             }
         }
     }
@@ -121,7 +131,8 @@ struct TileLoaderH {
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
                 int k = tid / (ROWS / 4) + KROWS * i;
-                *reinterpret_cast<uint2*>(lds + k * KM_LD + m4 * 4) = pack_bf16x4(r[i]);
+                if constexpr (HALF) *reinterpret_cast<uint2*>(lds + k * KM_LD + m4 * 4) = rh[i];
+                else *reinterpret_cast<uint2*>(lds + k * KM_LD + m4 * 4) = pack_bf16x4(r[i]);
             }
         }
     }
@@ -148,12 +159,12 @@ __device__ __forceinline__ bf16x8 frag_h(const __bf16* lds, int roff, int s, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool KGATHER, bool SWAP, bool AH = false, bool BH = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NT = 64 * WM * WN;
     static_assert(NT == 256 || NT == 512, "4 or 8 waves");
-    using LA = TileLoaderH<BM, AKM, false, NT>;
-    using LB = TileLoaderH<BN, BKM, KGATHER, NT>;
+    using LA = TileLoaderH<BM, AKM, false, NT, AH>;
+    using LB = TileLoaderH<BN, BKM, KGATHER, NT, BH>;
     constexpr int STAGE = LA::LDS_ELEMS + LB::LDS_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
 
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
+static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s, int ah = 0, int bh = 0) {
     p.tiles_x = cdiv(p.N, BN);
     p.tiles_y = cdiv(p.M, BM);
     const long ntiles = (long)p.tiles_x * p.tiles_y;
@@ -269,9 +280,25 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s) {
     const bool vec = gemm_vec_epilogue_ok(p);
     if constexpr (BM == 256) {  // built for the weight-gradient form only
         if (!(akm && bkm)) return set_err(DVAE_ERR_ARG, "gemm: the 256 x 256 tile is built for two K-major operands");
+        // bf16-STORED operands (the edge predictor's gradient tables, the state shadow): A alone or both
+#define DVAE_GEMM_LAUNCH_H(G_, BH_)                                                                                       \
+    do {                                                                                                                  \
+        if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, G_, true, true, BH_>), grid, block, 0, s, p);  \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, G_, false, true, BH_>), grid, block, 0, s, p);     \
+    } while (0)
+        if (bh && !ah) return set_err(DVAE_ERR_ARG, "gemm: a bf16-stored K-major B operand is built beside a bf16-stored A only");
+        if (ah) {
+            if (kg && bh) DVAE_GEMM_LAUNCH_H(true, true);
+            else if (kg) DVAE_GEMM_LAUNCH_H(true, false);
+            else if (bh) DVAE_GEMM_LAUNCH_H(false, true);
+            else DVAE_GEMM_LAUNCH_H(false, false);
+        } else
+#undef DVAE_GEMM_LAUNCH_H
         if (kg) DVAE_GEMM_LAUNCH(true, true, true);
         else DVAE_GEMM_LAUNCH(true, true, false);
     } else
+    if (ah || bh) return set_err(DVAE_ERR_ARG, "gemm: bf16-stored K-major operands are built for the 256 x 256 tile only");
+    else
     if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
     else if (!akm && bkm && !kg) DVAE_GEMM_LAUNCH(false, true, false);
     else if (akm && bkm && !kg) DVAE_GEMM_LAUNCH(true, true, false);
@@ -288,7 +315,8 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     {   // two K-contiguous operands, bf16- or fp32-stored: the large-tile kernels of gemm_bf16_nn.hip
         const int rc = gemm_bf16_nn(d, s);
         if (rc <= 0) return rc;
-        if (d.a_bf16 || d.b_bf16 || d.c_bf16)
+        // (bf16-stored K-major operands: the large weight-gradient form below, A or A and B)
+        if (d.c_bf16 || ((d.a_bf16 || d.b_bf16) && !(d.a_kmajor && d.b_kmajor && d.a_bf16)))
             return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored operands / outputs need two K-contiguous operands");
     }
     dvae_gemm_desc sub;
@@ -328,6 +356,10 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     if (!knob_256) use256 = false;
     if (knob_tile == 256) use256 = d.a_kmajor && d.b_kmajor && d.a_rows == nullptr;
     else if (knob_tile) use256 = false;
+    if (d.a_bf16) {  // bf16-stored K-major operands: this tile's loaders only, whatever the shape (a chunked product's tail)
+        if (!can_split || d.a_rows) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored K-major operands serve accumulating weight-gradient products only");
+        use256 = true;
+    }
     if (use256) {
         static const int cus = [] {
             int dev = 0, n = 0;
@@ -342,7 +374,9 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
         p.split_k = cdiv(d.K, p.k_per_split);
         if (knob_log)
             fprintf(stderr, "GEMMSELH 256x256 %d %d %d akm=1 bkm=1 split=%d br=%d\n", d.M, d.N, d.K, p.split_k, d.b_rows != nullptr);
-        return launch_cfg_h<256, 256, 2, 4>(p, d.a_kmajor, d.b_kmajor, s);
+        if ((d.a_bf16 && (d.lda % 4 || (uintptr_t)d.A % 8)) || (d.b_bf16 && (d.ldb % 4 || (uintptr_t)d.B % 8)))
+            return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored K-major operands need 8-byte aligned rows");
+        return launch_cfg_h<256, 256, 2, 4>(p, d.a_kmajor, d.b_kmajor, s, d.a_bf16, d.b_bf16);
     }
     if (knob_tile == 128) { use128 = true; small_m = false; }
     else if (knob_tile == 64) { use128 = false; small_m = false; }

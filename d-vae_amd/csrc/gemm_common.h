@@ -8,6 +8,7 @@ namespace dvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer offset past num_records: the load returns 0
 
 struct GemmParams {

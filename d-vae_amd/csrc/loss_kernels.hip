@@ -177,6 +177,11 @@ __device__ __forceinline__ float4 bf16x4_to_f4(uint2 r) {
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                        __uint_as_float(r.y & 0xffff0000u));
 }
+typedef __bf16 lbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 f4_to_bf16x4(float4 v) {  // round to nearest even, as the products' epilogues do
+    const lbf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return __builtin_bit_cast(uint2, b);
+}
 template <bool TH>
 struct PairRow;
 template <>
@@ -481,12 +486,16 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const int* __restrict__ c
 
 // Wide tables (HEp > 2048): a wave takes a QUARTER of a chunk's row (iterations 4 w .. 4 w + 3: one 16-bit half of a
 // mask word per pair), so that 16 accumulators per lane replace 64 (130 VGPRs, three waves per SIMD, before).
+// TH (bf16 mode, train.hip's edge_tables_bf16): rows written whole by their one chunk go to the bf16 table dtab_h, which
+// is what the data- and weight-gradient products read; rows shared by several chunks are still summed with fp32 atomics
+// in dtab and converted afterwards (pair_bwd_fix_kernel).
+template <bool TH>
 __global__ __launch_bounds__(256) void pair_bwd_split_kernel(const int* __restrict__ chunk_off,
                                                              const int* __restrict__ chunk_row,
                                                              const int* __restrict__ grp_pairs, const float* __restrict__ dl,
                                                              const uint32_t* __restrict__ mask, const float* __restrict__ w2,
                                                              const float* __restrict__ scale, float* __restrict__ dtab,
-                                                             int n_chunks, int HEp) {
+                                                             uint16_t* __restrict__ dtab_h, int n_chunks, int HEp) {
     constexpr int NW = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long waves_total = (long)gridDim.x * 4;
@@ -535,12 +544,46 @@ __global__ __launch_bounds__(256) void pair_bwd_split_kernel(const int* __restri
                 float* d = dtab + (long)row * HEp + c;
                 if (cr < 0) {
                     atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+                } else if (TH) {
+                    *reinterpret_cast<uint2*>(dtab_h + (long)row * HEp + c) = f4_to_bf16x4(v);
                 } else {
                     *reinterpret_cast<float4*>(d) = v;
                 }
             }
         }
     }
+}
+
+// bf16 tables: the rows the chunk passes summed with atomics (bit 31 of chunk_row), fp32 -> bf16, both tables in one
+// launch.  One wave per chunk; the first chunk of a row converts it.  Wave `nch` stands for the table's last row (the
+// no-input row, index NA / NB): zeros unless a chunk names it (chunks are sorted by row).
+__global__ __launch_bounds__(256) void pair_bwd_fix_kernel(const int* __restrict__ ca_row, int CA, const float* __restrict__ dea,
+                                                           uint16_t* __restrict__ dea_h, int NA, int blocks_a,
+                                                           const int* __restrict__ ch_row, int CH, const float* __restrict__ deb,
+                                                           uint16_t* __restrict__ deb_h, int NB, int HEp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int blk = blockIdx.x;
+    const int* rowv = ch_row;
+    const float* tab = deb;
+    uint16_t* tab_h = deb_h;
+    int nch = CH, last = NB;
+    if (blk < blocks_a) { rowv = ca_row; tab = dea; tab_h = dea_h; nch = CA; last = NA; }
+    else blk -= blocks_a;
+    const int q = blk * 4 + wave;
+    if (q > nch) return;
+    if (q == nch) {
+        if (nch > 0 && (rowv[nch - 1] & 0x7fffffff) == last) return;  // written by its chunk, or converted below
+        uint16_t* h = tab_h + (long)last * HEp;
+        for (int c = lane * 4; c < HEp; c += 256) *reinterpret_cast<uint2*>(h + c) = make_uint2(0u, 0u);
+        return;
+    }
+    const int cr = rowv[q];
+    if (cr >= 0) return;
+    const int row = cr & 0x7fffffff;
+    if (q > 0 && (rowv[q - 1] & 0x7fffffff) == row) return;
+    const float* d = tab + (long)row * HEp;
+    uint16_t* h = tab_h + (long)row * HEp;
+    for (int c = lane * 4; c < HEp; c += 256) *reinterpret_cast<uint2*>(h + c) = f4_to_bf16x4(ld4c(d + c));
 }
 
 __global__ void scale_inplace_kernel(float* x, const float* s, int n) {
@@ -846,9 +889,33 @@ extern "C" int dvae_pair_bce_fwd(const float* ea, const float* eb, const float* 
                               n_pairs, HEp, nullptr, 0u, 0.f, nullptr, stream, 0, 0);
 }
 
+namespace dvae {
+int pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs, const float* dl,
+                         const uint32_t* mask, const float* w2, const float* scale, float* dtab, int32_t n_chunks,
+                         int32_t HEp, hipStream_t stream, uint16_t* dtab_h);
+int pair_bwd_fix(const int* ca_row, int CA, const float* dea, uint16_t* dea_h, int NA, const int* ch_row, int CH,
+                 const float* deb, uint16_t* deb_h, int NB, int HEp, hipStream_t s) {
+    const int blocks_a = cdiv(CA + 1, 4), blocks_h = cdiv(CH + 1, 4);
+    DVAE_REQUIRE(HEp % 4 == 0 && (uintptr_t)dea_h % 8 == 0 && (uintptr_t)deb_h % 8 == 0, "pair_bwd_fix: misaligned table");
+    hipLaunchKernelGGL(pair_bwd_fix_kernel, dim3(blocks_a + blocks_h), dim3(256), 0, s, ca_row, CA, dea, dea_h, NA, blocks_a,
+                       ch_row, CH, deb, deb_h, NB, HEp);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+}  // namespace dvae
+
 extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,
                                          const float* dl, const uint32_t* mask, const float* w2, const float* scale,
                                          float* dtab, int32_t n_chunks, int32_t HEp, void* stream) {
+    return dvae::pair_bce_bwd_grouped(chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, dtab, n_chunks, HEp,
+                                      (hipStream_t)stream, nullptr);
+}
+
+// dtab_h (nullable; wide tables only): rows with one chunk are written there as bf16 instead (pair_bwd_fix converts the
+// others afterwards)
+int dvae::pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs,
+                               const float* dl, const uint32_t* mask, const float* w2, const float* scale, float* dtab,
+                               int32_t n_chunks, int32_t HEp, hipStream_t stream, uint16_t* dtab_h) {
     if (n_chunks == 0) return DVAE_OK;
     DVAE_REQUIRE(chunk_off && chunk_row && dl && mask && w2 && dtab, "pair_bce_bwd: null pointer");
     DVAE_REQUIRE(HEp > 0 && HEp % 4 == 0, "pair_bce_bwd: bad size");
@@ -861,11 +928,18 @@ extern "C" int dvae_pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t
     static const int knob_split = getenv("DVAE_PAIR_SPLIT") ? atoi(getenv("DVAE_PAIR_SPLIT")) : 1;
     if (nit == 16 && knob_split) {  // wide tables: a quarter row per wave
         grid.x = n_chunks < 16384 ? n_chunks : 16384;
-        hipLaunchKernelGGL(pair_bwd_split_kernel, grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, dtab,
-                           n_chunks, HEp);
+        if (dtab_h) {
+            DVAE_REQUIRE((uintptr_t)dtab_h % 8 == 0, "pair_bce_bwd: misaligned bf16 table");
+            hipLaunchKernelGGL(pair_bwd_split_kernel<true>, grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2,
+                               scale, dtab, dtab_h, n_chunks, HEp);
+        } else {
+            hipLaunchKernelGGL(pair_bwd_split_kernel<false>, grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2,
+                               scale, dtab, dtab_h, n_chunks, HEp);
+        }
         DVAE_LAUNCH_CHECK();
         return DVAE_OK;
     }
+    DVAE_REQUIRE(!dtab_h, "pair_bce_bwd: bf16 tables are built for the wide-table kernel only");
 #define DVAE_PAIR_BWD(N)                                                                                            \
     hipLaunchKernelGGL((pair_bwd_kernel<N>), grid, block, 0, s, chunk_off, chunk_row, grp_pairs, dl, mask, w2, scale, \
                        dtab, n_chunks, HEp)

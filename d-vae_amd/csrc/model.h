@@ -138,6 +138,12 @@ int pair_bce_fwd(const float* ea, const float* eb, const float* ec, const int32_
 int loss_bwd_init(const float* g3, float beta, float* gs, const float* dlogits, float* dlogits_s, long n_logits,
                   const int* ca_row, int CA, float* dea, int NA, const int* ch_row, int CH, float* deb, int NB, int HEp,
                   hipStream_t s);
+int pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, const int32_t* grp_pairs, const float* dl,
+                         const uint32_t* mask, const float* w2, const float* scale, float* dtab, int32_t n_chunks,
+                         int32_t HEp, hipStream_t stream, uint16_t* dtab_h);
+int pair_bwd_fix(const int* ca_row, int CA, const float* dea, uint16_t* dea_h, int NA, const int* ch_row, int CH,
+                 const float* deb, uint16_t* deb_h, int NB, int HEp, hipStream_t s);
+int segment_colsum_h(float* out, int ld_out, const uint16_t* x, int ld_x, int rows, int seg_rows, int width, hipStream_t s);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                     float* kld_sum, int B, int nz, int NZp, hipStream_t s, float* zero_a = nullptr, float* zero_b = nullptr,
                     int HEp = 0);

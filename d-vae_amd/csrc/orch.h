@@ -37,7 +37,12 @@ struct ModeGuard {
 // K loop), and a data gradient (B K-major = the weight as stored) reads the TRANSPOSED bf16 copy, which makes it a
 // product of two K-contiguous operands: both then run on gemm_bf16_nn.hip.  Anything the copies cannot serve
 // (alignment, a sub-block that does not start on 8 elements, a gathered B) stays as it is.
-static inline void use_bf16_weight_copy(dvae_gemm_desc& g) {
+static inline bool bf16_weight_copies_on() {
+    static const int knob = getenv("DVAE_BF16_WEIGHTS") ? atoi(getenv("DVAE_BF16_WEIGHTS")) : 1;
+    return knob != 0;
+}
+// always: also where a small accumulating product would rather split K over the fp32 weight (the caller has no fp32 A)
+static inline void use_bf16_weight_copy(dvae_gemm_desc& g, bool always = false) {
     static const int knob = getenv("DVAE_BF16_WEIGHTS") ? atoi(getenv("DVAE_BF16_WEIGHTS")) : 1;  // 0: off (A/B runs)
     const PackedLayout& L = tl_layout;
     if (!knob || !tl_pw || g.a_kmajor || g.b_rows || g.B < tl_pw || g.B >= tl_pw + L.total) return;
@@ -53,7 +58,7 @@ static inline void use_bf16_weight_copy(dvae_gemm_desc& g) {
     }
     // (a small accumulating data gradient is better off with split-K over the fp32 weight, gemm_bf16.hip: the
     // K-contiguous kernels do not split K)
-    if (g.accumulate && (long)cdiv(g.M, 64) * cdiv(g.N, 64) < 256) return;
+    if (!always && g.accumulate && (long)cdiv(g.M, 64) * cdiv(g.N, 64) < 256) return;
     for (int i = 0; i < L.nmats; ++i) {
         const PackedLayout::Mat& m = L.mats[i];
         if (off < m.off || off >= m.off + (size_t)m.rows * m.cols) continue;
@@ -96,33 +101,46 @@ static int lin_fwd(const float* X, int ldx, const int* xrows, const float* W, in
 // relu_out (nullable, laid out like dX): the layer's input was relu_out = ReLU(.), and dX is masked by relu_out > 0
 // dy_h (bf16 mode only, nullable): the bf16 shadow of dY (same row pitch in elements).  Used only when the product
 // will run on the transposed bf16 weight copy (two K-contiguous operands); otherwise the fp32 dY is read as before.
+// dy_h_only: there IS no complete fp32 dY (its producer stored bf16): the bf16 product or an error.
 static int lin_dgrad(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, const int* dxrows, int M,
-                     int N, int K, int acc, hipStream_t s, const float* relu_out = nullptr, const uint16_t* dy_h = nullptr) {
+                     int N, int K, int acc, hipStream_t s, const float* relu_out = nullptr, const uint16_t* dy_h = nullptr,
+                     bool dy_h_only = false) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.b_kmajor = 1; g.C = dX; g.ldc = ldx; g.c_rows = dxrows;
     g.M = M; g.N = K; g.K = N; g.accumulate = acc; g.relu_mask = relu_out;
     if (dy_h && tl_bf16) {
-        {  // small products stay exact fp32, as in run_gemm
+        if (!dy_h_only) {  // small products stay exact fp32, as in run_gemm
             const int rc = gemm_skinny(g, s, 0);
             if (rc != 1) return rc;
         }
         dvae_gemm_desc h = g;
-        use_bf16_weight_copy(h);
+        use_bf16_weight_copy(h, dy_h_only);
         if (h.b_bf16 && !h.b_kmajor) {  // the transposed copy serves it: A may be the shadow
             h.A = reinterpret_cast<const float*>(dy_h);
             h.a_bf16 = 1;
             return gemm_bf16(h, s);
         }
     }
+    if (dy_h_only) return set_err(DVAE_ERR_ARG, "lin_dgrad: a bf16-stored gradient needs the transposed bf16 weight copy");
     return run_gemm(g, s);
 }
 // dW[N x K] += dY[M x N]^T X[M x K]                    (weight gradient; dW must hold zeros / running sum)
 // xrows (nullable) gathers the rows of X; xrows_bound = rows of the stored X the list may name
+// dy_h (bf16 mode only, nullable): dY as its producer stored it in bf16 (same pitch in elements) -- the fp32 dY is then NOT
+// read (it may be incomplete); x_h (nullable, used only beside dy_h): the bf16 shadow of X.  Large weight-gradient shapes only
+// (gemm_bf16.hip's 256 x 256 tile): the caller passes them where the shapes are known to be.
 static int lin_wgrad(const float* dY, int ldy, const float* X, int ldx, const int* xrows, float* dW, int ldw, int M,
-                     int N, int K, hipStream_t s, int xrows_bound = 0, int max_split = 0) {
+                     int N, int K, hipStream_t s, int xrows_bound = 0, int max_split = 0, const uint16_t* dy_h = nullptr,
+                     const uint16_t* x_h = nullptr) {
     dvae_gemm_desc g = {};
     g.A = dY; g.lda = ldy; g.a_kmajor = 1; g.B = X; g.ldb = ldx; g.b_rows = xrows; g.b_kmajor = 1; g.C = dW; g.ldc = ldw;
     g.M = N; g.N = K; g.K = M; g.accumulate = 1; g.b_rows_bound = xrows_bound;
+    if (dy_h) {
+        if (!tl_bf16) return set_err(DVAE_ERR_ARG, "lin_wgrad: a bf16-stored gradient outside the bf16 mode");
+        g.A = reinterpret_cast<const float*>(dy_h); g.a_bf16 = 1;
+        if (x_h) { g.B = reinterpret_cast<const float*>(x_h); g.b_bf16 = 1; }
+        return gemm_bf16(g, s);
+    }
     return run_gemm(g, s, max_split);
 }
 

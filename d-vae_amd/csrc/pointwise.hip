@@ -275,8 +275,20 @@ __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, 
 
 // ---------------------------------------------------------------------------
 // out[seg][c] += sum_{rows of seg} x[row][c].  grid: (width/4/64, chunks, segs)
+// XH: x is stored as bf16 (a gradient table written so by its producer); ld_x counts elements either way.
+template <bool XH>
+__device__ __forceinline__ float4 ld4x(const void* x, long off) {
+    if constexpr (XH) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + off);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    } else {
+        return ld4(reinterpret_cast<const float*>(x) + off);
+    }
+}
+template <bool XH>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__ out, int ld_out,
-                                                             const float* __restrict__ x, int ld_x, int rows,
+                                                             const void* __restrict__ x, int ld_x, int rows,
                                                              int seg_rows, int w4, int rows_per_chunk) {
     __shared__ float4 red[4][64];
     int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -287,15 +299,15 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < w4) {
         // four independent row streams per thread keep 4 loads in flight (the loop is latency bound)
-        const float* base = x + c4 * 4;
+        const long base = c4 * 4;
         float4 a1 = acc, a2 = acc, a3 = acc;
         int r = r0 + ty;
         for (; r + 12 < r1; r += 16) {
-            float4 v0 = ld4(base + (long)r * ld_x), v1 = ld4(base + (long)(r + 4) * ld_x);
-            float4 v2 = ld4(base + (long)(r + 8) * ld_x), v3 = ld4(base + (long)(r + 12) * ld_x);
+            float4 v0 = ld4x<XH>(x, base + (long)r * ld_x), v1 = ld4x<XH>(x, base + (long)(r + 4) * ld_x);
+            float4 v2 = ld4x<XH>(x, base + (long)(r + 8) * ld_x), v3 = ld4x<XH>(x, base + (long)(r + 12) * ld_x);
             acc = add4(acc, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
         }
-        for (; r < r1; r += 4) acc = add4(acc, ld4(base + (long)r * ld_x));
+        for (; r < r1; r += 4) acc = add4(acc, ld4x<XH>(x, base + (long)r * ld_x));
         acc = add4(add4(acc, a1), add4(a2, a3));
     }
     red[ty][tx] = acc;
@@ -576,8 +588,19 @@ extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32
     return DVAE_OK;
 }
 
+static int segment_colsum_any(float* out, int32_t ld_out, const void* x, bool x_bf16, int32_t ld_x, int32_t rows,
+                              int32_t seg_rows, int32_t width, void* stream);
 extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                                        int32_t seg_rows, int32_t width, void* stream) {
+    return segment_colsum_any(out, ld_out, x, false, ld_x, rows, seg_rows, width, stream);
+}
+namespace dvae {
+int segment_colsum_h(float* out, int ld_out, const uint16_t* x, int ld_x, int rows, int seg_rows, int width, hipStream_t s) {
+    return segment_colsum_any(out, ld_out, x, true, ld_x, rows, seg_rows, width, s);
+}
+}  // namespace dvae
+static int segment_colsum_any(float* out, int32_t ld_out, const void* x, bool x_bf16, int32_t ld_x, int32_t rows,
+                              int32_t seg_rows, int32_t width, void* stream) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(out && x, "segment_colsum: null pointer");
     DVAE_REQUIRE(width > 0 && width % 4 == 0 && ld_x % 4 == 0 && seg_rows > 0, "segment_colsum: bad size");
@@ -591,8 +614,12 @@ extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* 
     if (chunks < 1) chunks = 1;
     int rpc = cdiv(seg_rows, chunks);
     chunks = cdiv(seg_rows, rpc);
-    hipLaunchKernelGGL(segment_colsum_kernel, dim3(cdiv(w4, 64), chunks, segs), dim3(256), 0, (hipStream_t)stream, out,
-                       ld_out, x, ld_x, rows, seg_rows, w4, rpc);
+    if (x_bf16)
+        hipLaunchKernelGGL(segment_colsum_kernel<true>, dim3(cdiv(w4, 64), chunks, segs), dim3(256), 0, (hipStream_t)stream,
+                           out, ld_out, x, ld_x, rows, seg_rows, w4, rpc);
+    else
+        hipLaunchKernelGGL(segment_colsum_kernel<false>, dim3(cdiv(w4, 64), chunks, segs), dim3(256), 0, (hipStream_t)stream,
+                           out, ld_out, x, ld_x, rows, seg_rows, w4, rpc);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

@@ -323,6 +323,13 @@ static bool edge_tables_bf16(const Dims& d) {
     static const int knob_split = [] { const char* v = getenv("DVAE_PAIR_SPLIT"); return v ? atoi(v) : 1; }();
     return knob && knob_split && d.bf16 && !d.bn && d.HEp > 2048 && d.HEp <= 4096 && d.HEp % 8 == 0;
 }
+// ... and then d EA / d EB too (DVAE_DTABLES_BF16=0: fp32): the pair backward writes bf16 rows, which the data- and
+// weight-gradient products and the bias column sum read.  They live in the upper halves of ea / eb's fp32-sized
+// allocations, which the bf16 tables leave unused.  Rows summed over several chunks still go through the fp32 tables.
+static bool edge_dtables_bf16(const Dims& d) {
+    static const int knob = [] { const char* v = getenv("DVAE_DTABLES_BF16"); return v ? atoi(v) : 1; }();
+    return knob && bf16_weight_copies_on() && edge_tables_bf16(d);
+}
 static DecWs carve_dec(const Dims& d, const dvae_batch_counts& c, float* base) {
     DecWs w;
     Bump b{base, 0};
@@ -1125,10 +1132,16 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
 
     // ---- edge predictor ------------------------------------------------------------
     // the forward left the ReLU masks: each pass is one sweep over (dl, mask) and writes its table
-    DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.ca_off, bv.ca_row, bv.ca_pairs, w.dl, w.mask, pw + L.we2, g_res, w.dea,
-                                       c->CA, HEp, s));
-    DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.ch_off, bv.ch_row, bv.ch_pairs, w.dl, w.mask, pw + L.we2, g_res, w.deb,
-                                       c->CH, HEp, s));
+    const bool dth = edge_dtables_bf16(d);
+    // the forward's bf16 shadow of the states (written on the unfused path only): the weight gradients' other operand
+    const uint16_t* const st_h = (!chain_fused(d, c->B) && !loss_fwd_tiny(d, *c)) ? w.st_h : nullptr;
+    uint16_t* const dea_h = dth ? reinterpret_cast<uint16_t*>(w.ea) + (size_t)(c->NA + 1) * HEp : nullptr;
+    uint16_t* const deb_h = dth ? reinterpret_cast<uint16_t*>(w.eb) + (size_t)(c->NB + 1) * HEp : nullptr;
+    DVAE_TRY(pair_bce_bwd_grouped(bv.ca_off, bv.ca_row, bv.ca_pairs, w.dl, w.mask, pw + L.we2, g_res, w.dea, c->CA, HEp,
+                                  s, dea_h));
+    DVAE_TRY(pair_bce_bwd_grouped(bv.ch_off, bv.ch_row, bv.ch_pairs, w.dl, w.mask, pw + L.we2, g_res, w.deb, c->CH, HEp,
+                                  s, deb_h));
+    if (dth) DVAE_TRY(pair_bwd_fix(bv.ca_row, c->CA, w.dea, dea_h, c->NA, bv.ch_row, c->CH, w.deb, deb_h, c->NB, HEp, s));
     if (d.bn) {
         DVAE_HIP(hipMemsetAsync(w.dec, 0, sizeof(float) * (size_t)B * HEp, s));
         DVAE_TRY(dvae_pair_bce_bwd_grouped(bv.cc_off, bv.cc_row, nullptr, w.dl, w.mask, pw + L.we2, g_res, w.dec,
@@ -1152,11 +1165,12 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         const int nblk = pair_blocks(c->NP, w.dw2_blocks);  // as the forward launched them
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, nblk, nblk, HEp, s2));
         DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
+        if (dth) DVAE_TRY(segment_colsum_h(pg + L.be1, HEp, dea_h, HEp, c->NA + 1, c->NA + 1, HEp, s2));
+        else DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
         DVAE_LAUNCH_CHECK();
-        DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2, NST));
-        DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2, NST));
+        DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2, NST, 0, dea_h, dth ? st_h : nullptr));
+        DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2, NST, 0, deb_h, dth ? st_h : nullptr));
         if (d.bn) DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s2));
         DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s2));
         DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s2));
@@ -1164,8 +1178,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         DVAE_TRY(lin_wgrad(w.dv1, d.HVp, w.vs, Hp, nullptr, pg + L.wv1, Hp, c->R, d.HVp, Hp, s2));
     }
     // data path continues on the main stream
-    DVAE_TRY(lin_dgrad(w.dea, HEp, pw + L.w1a, Hp, w.dst, Hp, bv.rowsA, c->NA, HEp, Hp, 1, s));
-    DVAE_TRY(lin_dgrad(w.deb, HEp, pw + L.w1b, Hp, w.dst, Hp, bv.rowsB, c->NB, HEp, Hp, 1, s));
+    DVAE_TRY(lin_dgrad(w.dea, HEp, pw + L.w1a, Hp, w.dst, Hp, bv.rowsA, c->NA, HEp, Hp, 1, s, nullptr, dea_h, dth));
+    DVAE_TRY(lin_dgrad(w.deb, HEp, pw + L.w1b, Hp, w.dst, Hp, bv.rowsB, c->NB, HEp, Hp, 1, s, nullptr, deb_h, dth));
     if (d.bn) DVAE_TRY(lin_dgrad(w.dec, HEp, pw + L.w1c, Hp, w.dh0c, Hp, nullptr, B, HEp, Hp, 0, s));
     DVAE_TRY(lin_dgrad(w.dv1, d.HVp, pw + L.wv1, Hp, w.dvs, Hp, nullptr, c->R, d.HVp, Hp, 0, s));
     DVAE_TRY(dvae_gather_sum_f32(w.dst, Hp, w.dvs, Hp, bv.vst_off, bv.vst_idx, nB, Hp, 1, s));
