@@ -143,6 +143,13 @@ int pair_bce_bwd_grouped(const int32_t* chunk_off, const int32_t* chunk_row, con
                          int32_t HEp, hipStream_t stream, uint16_t* dtab_h);
 int pair_bwd_fix(const int* ca_row, int CA, const float* dea, uint16_t* dea_h, int NA, const int* ch_row, int CH,
                  const float* deb, uint16_t* deb_h, int NB, int HEp, hipStream_t s);
+struct ColsumJobDesc {  // out[c] += scale * sum over rows of x[row][c]   (pointwise.hip: colsum_jobs)
+    float* out;
+    const void* x;       // fp32, or bf16 words when x_bf16
+    const float* scale;  // nullable: one device float
+    int ld_x, rows, width, x_bf16;
+};
+int colsum_jobs(const ColsumJobDesc* jobs, int n, hipStream_t s);
 int segment_colsum_h(float* out, int ld_out, const uint16_t* x, int ld_x, int rows, int seg_rows, int width, hipStream_t s);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                     float* kld_sum, int B, int nz, int NZp, hipStream_t s, float* zero_a = nullptr, float* zero_b = nullptr,

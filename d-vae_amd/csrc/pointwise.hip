@@ -4,6 +4,7 @@
 // float4 per lane, coalesced along the feature dimension.
 #include "common.h"
 #include "dvae_hip.h"
+#include "model.h"
 
 namespace dvae {
 
@@ -322,6 +323,52 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__
     }
 }
 
+// Several column sums in ONE launch (the bias gradients of the loss backward: four reductions whose inputs are all final at
+// the same point of the stream): blockIdx.z picks the job, each job has its own chunking; out[c] += scale * sum_rows x[row][c].
+struct ColsumJob {
+    float* out;
+    const void* x;
+    const float* scale;  // nullable: one device float
+    int ld_x, rows, w4, rows_per_chunk, chunks, x_bf16;
+};
+struct ColsumJobs {
+    ColsumJob j[4];
+};
+template <bool XH>
+__device__ __forceinline__ float4 colsum_rows(const void* x, int ld_x, long base, int r0, int r1, int ty) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), a1 = acc, a2 = acc, a3 = acc;
+    int r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+        float4 v0 = ld4x<XH>(x, base + (long)r * ld_x), v1 = ld4x<XH>(x, base + (long)(r + 4) * ld_x);
+        float4 v2 = ld4x<XH>(x, base + (long)(r + 8) * ld_x), v3 = ld4x<XH>(x, base + (long)(r + 12) * ld_x);
+        acc = add4(acc, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
+    }
+    for (; r < r1; r += 4) acc = add4(acc, ld4x<XH>(x, base + (long)r * ld_x));
+    return add4(add4(acc, a1), add4(a2, a3));
+}
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(ColsumJobs J) {
+    __shared__ float4 red[4][64];
+    const ColsumJob& jb = J.j[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= jb.w4 || (int)blockIdx.y >= jb.chunks) return;  // (whole workgroups: before the barrier)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * jb.rows_per_chunk, r1 = min(r0 + jb.rows_per_chunk, jb.rows);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < jb.w4)
+        acc = jb.x_bf16 ? colsum_rows<true>(jb.x, jb.ld_x, c4 * 4L, r0, r1, ty) : colsum_rows<false>(jb.x, jb.ld_x, c4 * 4L, r0, r1, ty);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c4 < jb.w4) {
+        acc = add4(add4(red[0][tx], red[1][tx]), add4(red[2][tx], red[3][tx]));
+        const float sc = jb.scale ? jb.scale[0] : 1.f;
+        float* o = jb.out + c4 * 4;
+        atomicAdd(o + 0, acc.x * sc);
+        atomicAdd(o + 1, acc.y * sc);
+        atomicAdd(o + 2, acc.z * sc);
+        atomicAdd(o + 3, acc.w * sc);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Rows sorted by vertex type (counting sort, ONE workgroup): off[T + 1], idx[na + nb].  The rows
 // are those of two type arrays laid end to end (slots, then the decoder's partial rows).
@@ -590,6 +637,35 @@ extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32
 
 static int segment_colsum_any(float* out, int32_t ld_out, const void* x, bool x_bf16, int32_t ld_x, int32_t rows,
                               int32_t seg_rows, int32_t width, void* stream);
+namespace dvae {
+// up to four column sums as one launch; jobs with no rows are skipped
+int colsum_jobs(const ColsumJobDesc* jobs, int n, hipStream_t s) {
+    DVAE_REQUIRE(jobs && n >= 0 && n <= 4, "colsum_jobs: 0 .. 4 jobs");
+    ColsumJobs J = {};
+    int nj = 0, gx = 1, gy = 1;
+    for (int i = 0; i < n; ++i) {
+        const ColsumJobDesc& d = jobs[i];
+        if (d.rows == 0) continue;
+        DVAE_REQUIRE(d.out && d.x && d.rows > 0, "colsum_jobs: null pointer");
+        DVAE_REQUIRE(d.width > 0 && d.width % 4 == 0 && d.ld_x % 4 == 0 && (uintptr_t)d.x % (d.x_bf16 ? 8 : 16) == 0,
+                     "colsum_jobs: bad size or alignment");
+        ColsumJob& j = J.j[nj++];
+        j.out = d.out; j.x = d.x; j.scale = d.scale; j.ld_x = d.ld_x; j.rows = d.rows; j.w4 = d.width / 4; j.x_bf16 = d.x_bf16;
+        const int xb = cdiv(j.w4, 64);
+        int chunks = cdiv(d.rows, 32);  // as dvae_segment_colsum_f32: >= 2 workgroups per CU where the rows allow
+        const int cap = cdiv(768, xb);
+        if (chunks > cap) chunks = cap;
+        j.rows_per_chunk = cdiv(d.rows, chunks);
+        j.chunks = cdiv(d.rows, j.rows_per_chunk);
+        if (xb > gx) gx = xb;
+        if (j.chunks > gy) gy = j.chunks;
+    }
+    if (nj == 0) return DVAE_OK;
+    hipLaunchKernelGGL(colsum_jobs_kernel, dim3(gx, gy, nj), dim3(256), 0, s, J);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+}
+}  // namespace dvae
 extern "C" int dvae_segment_colsum_f32(float* out, int32_t ld_out, const float* x, int32_t ld_x, int32_t rows,
                                        int32_t seg_rows, int32_t width, void* stream) {
     return segment_colsum_any(out, ld_out, x, false, ld_x, rows, seg_rows, width, stream);

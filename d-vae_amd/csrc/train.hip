@@ -1163,18 +1163,20 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         // run on this stream at the end: a one-workgroup kernel bound by latency, kept off the main stream
         DVAE_TRY(dvae_type_csr(bv.types, nB, bv.p_type, PT, d.T, reinterpret_cast<int*>(w.xoh), reinterpret_cast<int*>(w.xoh) + 40, s2));
         const int nblk = pair_blocks(c->NP, w.dw2_blocks);  // as the forward launched them
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.we2, HEp, w.dw2p, HEp, nblk, nblk, HEp, s2));
-        DVAE_TRY(scale_inplace(pg + L.we2, g_res, HEp, s2));  // the forward's partials are unscaled
-        if (dth) DVAE_TRY(segment_colsum_h(pg + L.be1, HEp, dea_h, HEp, c->NA + 1, c->NA + 1, HEp, s2));
-        else DVAE_TRY(dvae_segment_colsum_f32(pg + L.be1, HEp, w.dea, HEp, c->NA + 1, c->NA + 1, HEp, s2));
+        // the four bias-like gradients whose inputs are final here, as one launch: d we2 (the forward's partials are
+        // unscaled), d be1, d bv2, d bv1
+        const ColsumJobDesc bias_jobs[4] = {
+            {pg + L.we2, w.dw2p, g_res, HEp, nblk, HEp, 0},
+            {pg + L.be1, dth ? (const void*)dea_h : (const void*)w.dea, nullptr, HEp, c->NA + 1, HEp, dth ? 1 : 0},
+            {pg + L.bv2, w.dlogits_s, nullptr, d.Tp, c->R, d.Tp, 0},
+            {pg + L.bv1, w.dv1, nullptr, d.HVp, c->R, d.HVp, 0}};
+        DVAE_TRY(colsum_jobs(bias_jobs, 4, s2));
         hipLaunchKernelGGL(sum_scaled_kernel, dim3(64), dim3(256), 0, s2, w.dl, c->NP, g_res, pg + L.be2);
         DVAE_LAUNCH_CHECK();
         DVAE_TRY(lin_wgrad(w.dea, HEp, w.st, Hp, bv.rowsA, pg + L.w1a, Hp, c->NA, HEp, Hp, s2, NST, 0, dea_h, dth ? st_h : nullptr));
         DVAE_TRY(lin_wgrad(w.deb, HEp, w.st, Hp, bv.rowsB, pg + L.w1b, Hp, c->NB, HEp, Hp, s2, NST, 0, deb_h, dth ? st_h : nullptr));
         if (d.bn) DVAE_TRY(lin_wgrad(w.dec, HEp, w.agg, Hp, nullptr, pg + L.w1c, Hp, B, HEp, Hp, s2));
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv2, d.Tp, w.dlogits_s, d.Tp, c->R, c->R, d.Tp, s2));
         DVAE_TRY(lin_wgrad(w.dlogits_s, d.Tp, w.v1, d.HVp, nullptr, pg + L.wv2, d.HVp, c->R, d.Tp, d.HVp, s2));
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.bv1, d.HVp, w.dv1, d.HVp, c->R, c->R, d.HVp, s2));
         DVAE_TRY(lin_wgrad(w.dv1, d.HVp, w.vs, Hp, nullptr, pg + L.wv1, Hp, c->R, d.HVp, Hp, s2));
     }
     // data path continues on the main stream
