@@ -62,10 +62,12 @@ typedef struct dvae_gemm_desc {
                                b_rows is below it).  Required there: K-major operands are addressed with 32-bit byte
                                offsets, and a gather cannot be rebased chunk by chunk, so b_rows_bound * ldb * 4 must
                                stay below 4 GiB or the call is refused.  Ignored otherwise. */
-    int32_t a_bf16, b_bf16; /* dvae_gemm_bf16 only, K-contiguous operands only: the operand is STORED as bf16 (A / B then
-                               point at uint16 bf16 words, lda / ldb count bf16 elements; 16-byte aligned rows,
-                               K % 8 == 0).  Half the operand bytes and no conversion in the K loop: see
-                               gemm_bf16_nn.hip.  dvae_gemm_f32 refuses them. */
+    int32_t a_bf16, b_bf16; /* dvae_gemm_bf16 only: the operand is STORED as bf16 (A / B then point at uint16 bf16 words,
+                               lda / ldb count bf16 elements).  Two K-contiguous operands, either or both stored so
+                               (16-byte aligned rows, K % 8 == 0; gemm_bf16_nn.hip), or the weight-gradient form -- two
+                               K-major operands, accumulate, no bias / activation -- with a_bf16 and optionally b_bf16
+                               (8-byte aligned rows; gemm_bf16.hip's 256 x 256 tile, whatever the shape).  Half the
+                               operand bytes and no conversion in the K loop.  dvae_gemm_f32 refuses them. */
     int32_t c_bf16;         /* dvae_gemm_bf16 only, products of two K-contiguous operands only: C is STORED as bf16 (C then
                                points at uint16 bf16 words, ldc counts bf16 elements; 8-byte aligned rows, N % 4 == 0;
                                bias and c_rows allowed; no activation, accumulate or relu_mask).  For outputs that only
