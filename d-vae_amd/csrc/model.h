@@ -114,18 +114,22 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s);
 int gemm_skinny(const dvae_gemm_desc& d, hipStream_t s, int force_nt);  // gemm_skinny.hip: products of few rows; 1 = not served there
 int scale_inplace(float* x, const float* s, int n, hipStream_t st);
 int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
-                    float* ghn_out, int rows, int Hp, hipStream_t s, uint16_t* hout_h = nullptr);
-// the pointwise kernels with a bf16 SHADOW of their output beside it (pointwise.hip; nullable)
+                    float* ghn_out, int rows, int Hp, hipStream_t s, uint16_t* hout_h = nullptr, int hg = 0);
+// the pointwise kernels with a bf16 SHADOW of their output beside it (pointwise.hip; nullable); pre / hg: the HALF-GATES
+// form (bf16 pre-activations in, bf16 saved gates: pointwise.hip ldg4 / stg4, train.hip half_gates())
 int gather_sum_h(float* out, int ld_out, const float* src, int ld_src, const int* off, const int* idx, int rows, int width,
                  int accumulate, uint16_t* out_h, hipStream_t s);
 int gru_pointwise_fwd_h(float* gh, const float* gi_tab, const int* types, const float* bhn, const float* hprev, int ld_hprev,
-                        float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s);
+                        float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s,
+                        const uint16_t* pre = nullptr);
 int gru_pointwise_bwd_h(const float* dh, int ld_dh, const float* gates, const float* ghn, const float* hprev, int ld_hprev,
-                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s);
+                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s,
+                        int hg = 0);
 int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx, const float* dagg2, const int* off2,
-                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s);
+                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s, int hg = 0);
 int gated_fwd_gather_h(float* gm, const float* gv_row, float* msg, int ld_msg, int cur_row0, float* next_agg, int ld_agg,
-                       const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s);
+                       const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s,
+                       const uint16_t* pre = nullptr);
 int loss_fwd_init(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                   float* sums, float* zero_row_a, float* zero_row_b, int HEp, int B, int nz, int NZp, hipStream_t s);
 int vertex_ce_blocks(int R);

@@ -20,6 +20,25 @@ __device__ __forceinline__ void st4h(uint16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, b);
 }
 
+// HALF GATES (round 3, bf16 mode, train.hip: half_gates()): what a level's product hands to its tail (the pre-activations)
+// and what the forward tails save for the backward ones (r, z, n, gh_n; g, m) is stored as bf16.  The kernels below take
+// the same pointers either way; with HG they address 2-byte elements behind them (the caller offsets them in elements).
+template <bool HG>
+__device__ __forceinline__ float4 ldg4(const float* base, long e) {
+    if constexpr (HG) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + e);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    } else {
+        return ld4(base + e);
+    }
+}
+template <bool HG>
+__device__ __forceinline__ void stg4(float* base, long e, float4 v) {
+    if constexpr (HG) st4h(reinterpret_cast<uint16_t*>(base) + e, v);
+    else st4(base + e, v);
+}
+
 // ---------------------------------------------------------------------------
 __global__ void gather_sum_kernel(float* __restrict__ out, int ld_out, const float* __restrict__ src, int ld_src,
                                   const int* __restrict__ off, const int* __restrict__ idx, int rows, int w4,
@@ -57,17 +76,20 @@ __global__ void scatter_rows_add_kernel(float* __restrict__ dst, int ld_dst, con
 }
 
 // ---------------------------------------------------------------------------
+// HG: the pre-activations come from `pre` (bf16, [rows][3 Hp]); gates and gh_n are saved as bf16
+template <bool HG>
 __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__ gi_tab, const int* __restrict__ types,
                                const float* __restrict__ bhn, const float* __restrict__ hprev, int ld_hprev,
                                float* __restrict__ hout, int ld_hout, float* __restrict__ ghn_out, int rows, int Hp,
-                               uint16_t* __restrict__ hout_h) {
+                               uint16_t* __restrict__ hout_h, const float* __restrict__ pre) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / w4), c = (int)(i % w4) * 4;
-        float* g = gh + (long)r * 3 * Hp;
+        const long g0 = (long)r * 3 * Hp;
+        const float* src = HG ? pre : gh;
         const float* gi = gi_tab + (long)types[r] * 3 * Hp;
-        float4 ghr = ld4(g + c), ghz = ld4(g + Hp + c), ghn = ld4(g + 2 * Hp + c);
+        float4 ghr = ldg4<HG>(src, g0 + c), ghz = ldg4<HG>(src, g0 + Hp + c), ghn = ldg4<HG>(src, g0 + 2 * Hp + c);
         float4 gir = ld4(gi + c), giz = ld4(gi + Hp + c), gin = ld4(gi + 2 * Hp + c);
         float4 bn = ld4(bhn + c);
         float4 hp = hprev ? ld4(hprev + (long)r * ld_hprev + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -83,10 +105,10 @@ __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__
     }
         GRU1(x) GRU1(y) GRU1(z) GRU1(w)
 #undef GRU1
-        st4(g + c, R);
-        st4(g + Hp + c, Z);
-        st4(g + 2 * Hp + c, N);
-        st4(ghn_out + (long)r * Hp + c, GN);
+        stg4<HG>(gh, g0 + c, R);
+        stg4<HG>(gh, g0 + Hp + c, Z);
+        stg4<HG>(gh, g0 + 2 * Hp + c, N);
+        stg4<HG>(ghn_out, (long)r * Hp + c, GN);
         st4(hout + (long)r * ld_hout + c, Hn);
         if (hout_h) st4h(hout_h + (long)r * ld_hout + c, Hn);
     }
@@ -95,6 +117,7 @@ __global__ void gru_fwd_kernel(float* __restrict__ gh, const float* __restrict__
 // The first level of an encoder pass: no predecessors, so h_prev = 0 and the hidden product is 0 (models.py:682 with
 // H = zeros).  Same arithmetic as gru_fwd_kernel on a zero gh / zero h_prev, without reading either; also leaves the
 // zeros the backward pass expects in the level's agg rows (its h_prev) -- one launch instead of two memsets + one.
+template <bool HG>
 __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __restrict__ gi_tab,
                                      const int* __restrict__ types, const float* __restrict__ bhn,
                                      float* __restrict__ agg_zero, float* __restrict__ hout, float* __restrict__ ghn_out,
@@ -103,7 +126,7 @@ __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __r
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / w4), c = (int)(i % w4) * 4;
-        float* g = gates + (long)r * 3 * Hp;
+        const long g0 = (long)r * 3 * Hp;
         const float* gi = gi_tab + (long)types[r] * 3 * Hp;
         float4 gir = ld4(gi + c), giz = ld4(gi + Hp + c), gin = ld4(gi + 2 * Hp + c);
         float4 bn = ld4(bhn + c);
@@ -119,16 +142,17 @@ __global__ void gru_fwd_first_kernel(float* __restrict__ gates, const float* __r
     }
         GRU0(x) GRU0(y) GRU0(z) GRU0(w)
 #undef GRU0
-        st4(g + c, R);
-        st4(g + Hp + c, Z);
-        st4(g + 2 * Hp + c, N);
-        st4(ghn_out + (long)r * Hp + c, bn);
+        stg4<HG>(gates, g0 + c, R);
+        stg4<HG>(gates, g0 + Hp + c, Z);
+        stg4<HG>(gates, g0 + 2 * Hp + c, N);
+        stg4<HG>(ghn_out, (long)r * Hp + c, bn);
         st4(hout + (long)r * Hp + c, Hn);
         if (hout_h) st4h(hout_h + (long)r * Hp + c, Hn);
         st4(agg_zero + (long)r * Hp + c, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
+template <bool HG>
 __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const float* __restrict__ gates,
                                const float* __restrict__ ghn, const float* __restrict__ hprev, int ld_hprev,
                                float* __restrict__ dgh, float* __restrict__ dgin, float* __restrict__ dhprev,
@@ -137,9 +161,9 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const fl
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / w4), c = (int)(i % w4) * 4;
-        const float* g = gates + (long)r * 3 * Hp;
-        float4 R = ld4(g + c), Z = ld4(g + Hp + c), N = ld4(g + 2 * Hp + c);
-        float4 GN = ld4(ghn + (long)r * Hp + c);
+        const long g0 = (long)r * 3 * Hp;
+        float4 R = ldg4<HG>(gates, g0 + c), Z = ldg4<HG>(gates, g0 + Hp + c), N = ldg4<HG>(gates, g0 + 2 * Hp + c);
+        float4 GN = ldg4<HG>(ghn, (long)r * Hp + c);
         float4 D = ld4(dh + (long)r * ld_dh + c);
         float4 hp = hprev ? ld4(hprev + (long)r * ld_hprev + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 dR, dZ, dGN, dPN, dHP;
@@ -214,22 +238,24 @@ __global__ void gated_bwd_kernel(const float* __restrict__ dmsg, int ld_dmsg, co
 // CSR gather-sum that feeds the NEXT level: both are independent per feature column, and every
 // source slot of graph b's next vertex lies in graph b, so the only not-yet-stored message a lane
 // needs is the one it has just computed (slot cur_row0 + b), which it keeps in registers.
+template <bool HG>
 __global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __restrict__ gv, float* __restrict__ msg,
                                         int ld_msg, int cur_row0, float* __restrict__ next_agg, int ld_agg,
                                         const int* __restrict__ next_off, const int* __restrict__ idx, int rows,
-                                        int Hp, uint16_t* __restrict__ next_agg_h) {
+                                        int Hp, uint16_t* __restrict__ next_agg_h, const float* __restrict__ pre) {
     int w4 = Hp / 4;
     long total = (long)rows * w4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int r = (int)(i / w4), c = (int)(i % w4) * 4;
-        float* p = gm + (long)r * 2 * Hp;
-        float4 a = add4(ld4(p + c), ld4(gv + c));
-        float4 m = add4(ld4(p + Hp + c), ld4(gv + Hp + c));
+        const long p0 = (long)r * 2 * Hp;
+        const float* src = HG ? pre : gm;
+        float4 a = add4(ldg4<HG>(src, p0 + c), ld4(gv + c));
+        float4 m = add4(ldg4<HG>(src, p0 + Hp + c), ld4(gv + Hp + c));
         float4 g = make_float4(1.f / (1.f + expf(-a.x)), 1.f / (1.f + expf(-a.y)), 1.f / (1.f + expf(-a.z)),
                                1.f / (1.f + expf(-a.w)));
         float4 own = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);
-        st4(p + c, g);
-        st4(p + Hp + c, m);
+        stg4<HG>(gm, p0 + c, g);
+        stg4<HG>(gm, p0 + Hp + c, m);
         st4(msg + (long)(cur_row0 + r) * ld_msg + c, own);
         if (next_agg) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -245,6 +271,7 @@ __global__ void gated_fwd_gather_kernel(float* __restrict__ gm, const float* __r
 
 // backward twin: d msg of a level = CSR gather-sum of the consumers' d agg rows (one or two lists),
 // consumed in registers by the gate/mapper pointwise backward; d msg itself is never stored.
+template <bool HG>
 __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, const int* __restrict__ off,
                                         const int* __restrict__ idx, const float* __restrict__ dagg2,
                                         const int* __restrict__ off2, const int* __restrict__ idx2,
@@ -258,8 +285,8 @@ __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, 
         for (int k = off[r]; k < off[r + 1]; ++k) d = add4(d, ld4(dagg + (long)idx[k] * ld + c));
         if (off2)
             for (int k = off2[r]; k < off2[r + 1]; ++k) d = add4(d, ld4(dagg2 + (long)idx2[k] * ld + c));
-        const float* p = gm + (long)r * 2 * Hp;
-        float4 g = ld4(p + c), m = ld4(p + Hp + c);
+        const long p0 = (long)r * 2 * Hp;
+        float4 g = ldg4<HG>(gm, p0 + c), m = ldg4<HG>(gm, p0 + Hp + c);
         float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
                                 d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
         float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
@@ -489,14 +516,21 @@ extern "C" int dvae_scatter_rows_add_f32(float* dst, int32_t ld_dst, const float
 
 namespace dvae {
 // hout_h (nullable): bf16 shadow of the new states, row pitch ld_hout elements
+// pre (nullable): HALF-GATES form -- the pre-activations are read from `pre` (bf16 words, [rows][3 Hp]) and gh / ghn_out
+// point at bf16 words too (see ldg4 / stg4)
 int gru_pointwise_fwd_h(float* gh, const float* gi_tab, const int* types, const float* bhn, const float* hprev, int ld_hprev,
-                        float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s) {
+                        float* hout, int ld_hout, float* ghn_out, int rows, int Hp, uint16_t* hout_h, hipStream_t s,
+                        const uint16_t* pre) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(gh && gi_tab && types && bhn && hout && ghn_out, "gru_pointwise_fwd: null pointer");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_hout % 4 == 0 && (!hprev || ld_hprev % 4 == 0), "gru_pointwise_fwd: bad Hp/ld");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gh, gi_tab, types, bhn, hprev, ld_hprev, hout,
-                       ld_hout, ghn_out, rows, Hp, hout_h);
+    if (pre)
+        hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, s, gh, gi_tab, types, bhn, hprev, ld_hprev,
+                           hout, ld_hout, ghn_out, rows, Hp, hout_h, reinterpret_cast<const float*>(pre));
+    else
+        hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, s, gh, gi_tab, types, bhn, hprev, ld_hprev,
+                           hout, ld_hout, ghn_out, rows, Hp, hout_h, (const float*)nullptr);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -505,16 +539,20 @@ extern "C" int dvae_gru_pointwise_fwd(float* gh, const float* gi_tab, const int3
                                       const float* hprev, int32_t ld_hprev, float* hout, int32_t ld_hout,
                                       float* ghn_out, int32_t rows, int32_t Hp, void* stream) {
     return dvae::gru_pointwise_fwd_h(gh, gi_tab, types, bhn, hprev, ld_hprev, hout, ld_hout, ghn_out, rows, Hp, nullptr,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, nullptr);
 }
 
 namespace dvae {
 int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, const float* bhn, float* agg_zero, float* hout,
-                    float* ghn_out, int rows, int Hp, hipStream_t s, uint16_t* hout_h) {
+                    float* ghn_out, int rows, int Hp, hipStream_t s, uint16_t* hout_h, int hg) {
     if (rows == 0) return DVAE_OK;
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gru_fwd_first_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gates, gi_tab, types, bhn, agg_zero,
-                       hout, ghn_out, rows, Hp, hout_h);
+    if (hg)
+        hipLaunchKernelGGL(gru_fwd_first_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, s, gates, gi_tab, types, bhn, agg_zero,
+                           hout, ghn_out, rows, Hp, hout_h);
+    else
+        hipLaunchKernelGGL(gru_fwd_first_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, s, gates, gi_tab, types, bhn, agg_zero,
+                           hout, ghn_out, rows, Hp, hout_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -522,14 +560,20 @@ int gru_first_level(float* gates, const float* gi_tab, const int32_t* types, con
 
 namespace dvae {
 // dgh_h (nullable): bf16 shadow of d gh, row pitch 3 Hp elements
+// hg: gates / ghn point at bf16 words (HALF-GATES form)
 int gru_pointwise_bwd_h(const float* dh, int ld_dh, const float* gates, const float* ghn, const float* hprev, int ld_hprev,
-                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s) {
+                        float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s,
+                        int hg) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(dh && gates && ghn && dgh && dgin, "gru_pointwise_bwd: null pointer");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_dh % 4 == 0, "gru_pointwise_bwd: bad Hp/ld");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, s, dh, ld_dh, gates, ghn, hprev, ld_hprev, dgh,
-                       dgin, dhprev, ld_dhprev, rows, Hp, dgh_h);
+    if (hg)
+        hipLaunchKernelGGL(gru_bwd_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, s, dh, ld_dh, gates, ghn, hprev, ld_hprev,
+                           dgh, dgin, dhprev, ld_dhprev, rows, Hp, dgh_h);
+    else
+        hipLaunchKernelGGL(gru_bwd_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, s, dh, ld_dh, gates, ghn, hprev, ld_hprev,
+                           dgh, dgin, dhprev, ld_dhprev, rows, Hp, dgh_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -538,7 +582,7 @@ extern "C" int dvae_gru_pointwise_bwd(const float* dh, int32_t ld_dh, const floa
                                       const float* hprev, int32_t ld_hprev, float* dgh, float* dgin, float* dhprev,
                                       int32_t ld_dhprev, int32_t rows, int32_t Hp, void* stream) {
     return dvae::gru_pointwise_bwd_h(dh, ld_dh, gates, ghn, hprev, ld_hprev, dgh, dgin, dhprev, ld_dhprev, rows, Hp, nullptr,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, 0);
 }
 
 extern "C" int dvae_gated_pointwise_fwd(float* gm, const float* gv, float* msg, int32_t ld_msg, int32_t rows,
@@ -567,16 +611,23 @@ extern "C" int dvae_gated_pointwise_bwd(const float* dmsg, int32_t ld_dmsg, cons
 
 namespace dvae {
 // next_agg_h (nullable): bf16 shadow of the next level's predecessor sums, row pitch ld_agg elements
+// pre (nullable): HALF-GATES form -- pre-activations from `pre` (bf16 words, [rows][2 Hp]), gm points at bf16 words
 int gated_fwd_gather_h(float* gm, const float* gv_row, float* msg, int ld_msg, int cur_row0, float* next_agg, int ld_agg,
-                       const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s) {
+                       const int* next_off, const int* idx, int rows, int Hp, uint16_t* next_agg_h, hipStream_t s,
+                       const uint16_t* pre) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(gm && gv_row && msg, "gated_fwd_gather: null pointer");
     DVAE_REQUIRE(!next_agg || (next_off && idx), "gated_fwd_gather: the next level's CSR lists are missing");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_msg % 4 == 0 && (!next_agg || ld_agg % 4 == 0) && cur_row0 >= 0,
                  "gated_fwd_gather: bad size");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gated_fwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, s, gm, gv_row, msg, ld_msg, cur_row0,
-                       next_agg, ld_agg, next_off, idx, rows, Hp, next_agg ? next_agg_h : nullptr);
+    if (pre)
+        hipLaunchKernelGGL(gated_fwd_gather_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, s, gm, gv_row, msg, ld_msg, cur_row0,
+                           next_agg, ld_agg, next_off, idx, rows, Hp, next_agg ? next_agg_h : nullptr,
+                           reinterpret_cast<const float*>(pre));
+    else
+        hipLaunchKernelGGL(gated_fwd_gather_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, s, gm, gv_row, msg, ld_msg, cur_row0,
+                           next_agg, ld_agg, next_off, idx, rows, Hp, next_agg ? next_agg_h : nullptr, (const float*)nullptr);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -585,20 +636,25 @@ extern "C" int dvae_gated_fwd_gather(float* gm, const float* gv_row, float* msg,
                                      float* next_agg, int32_t ld_agg, const int32_t* next_off, const int32_t* idx,
                                      int32_t rows, int32_t Hp, void* stream) {
     return dvae::gated_fwd_gather_h(gm, gv_row, msg, ld_msg, cur_row0, next_agg, ld_agg, next_off, idx, rows, Hp, nullptr,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, nullptr);
 }
 
 namespace dvae {
 // dgm_h (nullable): bf16 shadow of d gm, row pitch 2 Hp elements
+// hg: gm points at bf16 words (HALF-GATES form)
 int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx, const float* dagg2, const int* off2,
-                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s) {
+                       const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s, int hg) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(dagg && off && idx && gm && dgm, "gated_bwd_gather: null pointer");
     DVAE_REQUIRE(!off2 || (dagg2 && idx2), "gated_bwd_gather: second list incomplete");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld % 4 == 0, "gated_bwd_gather: bad size");
     long total = (long)rows * (Hp / 4);
-    hipLaunchKernelGGL(gated_bwd_gather_kernel, dim3(ew_grid(total)), dim3(256), 0, s, dagg, ld, off, idx, dagg2, off2, idx2,
-                       gm, dgm, rows, Hp, dgm_h);
+    if (hg)
+        hipLaunchKernelGGL(gated_bwd_gather_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, s, dagg, ld, off, idx, dagg2, off2,
+                           idx2, gm, dgm, rows, Hp, dgm_h);
+    else
+        hipLaunchKernelGGL(gated_bwd_gather_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, s, dagg, ld, off, idx, dagg2, off2,
+                           idx2, gm, dgm, rows, Hp, dgm_h);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
@@ -606,7 +662,7 @@ int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx
 extern "C" int dvae_gated_bwd_gather(const float* dagg, int32_t ld, const int32_t* off, const int32_t* idx,
                                      const float* dagg2, const int32_t* off2, const int32_t* idx2, const float* gm,
                                      float* dgm, int32_t rows, int32_t Hp, void* stream) {
-    return dvae::gated_bwd_gather_h(dagg, ld, off, idx, dagg2, off2, idx2, gm, dgm, rows, Hp, nullptr, (hipStream_t)stream);
+    return dvae::gated_bwd_gather_h(dagg, ld, off, idx, dagg2, off2, idx2, gm, dgm, rows, Hp, nullptr, (hipStream_t)stream, 0);
 }
 
 extern "C" int dvae_type_csr(const int32_t* types_a, int32_t na, const int32_t* types_b, int32_t nb, int32_t T,

@@ -499,6 +499,23 @@ static bool chain_fused_bwd(const Dims& d, int B) {
                                         B <= chain_tiny_rows()))) && !d.bn;
 }
 
+// HALF GATES (round 3; bf16 mode, the unfused path of large levels -- wherever act_shadows() is on and neither chain runs
+// fused level kernels; DVAE_GATES_BF16=0: off).  The level products write their pre-activations as bf16 (c_bf16) into the
+// UPPER half of the fp32-sized gates / gm allocation, the forward tails read them from there and save r, z, n, gh_n /
+// g, m as bf16 in the LOWER half (ghn: the lower half of its allocation), the backward tails read those.  Rows keep their
+// indices; only the element size changes (hoff / pre_of below).  ~16 of the ~38 KB a GRU row moves forward, ~8 of ~50 backward.
+static bool half_gates(const Dims& d, int B) {
+    static const int knob = [] { const char* v = getenv("DVAE_GATES_BF16"); return v ? atoi(v) : 1; }();
+    return knob && act_shadows(d, B) && bf16_weight_copies_on() && !chain_fused(d, B) && !chain_fused_bwd(d, B);
+}
+static inline float* hoff(float* base, size_t elems, bool hg) {
+    return hg ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + elems) : base + elems;
+}
+// row `elems / width` of the pre-activation scratch behind an allocation of `total` fp32 elements
+static inline uint16_t* pre_of(float* base, size_t total, size_t elems, bool hg) {
+    return hg ? reinterpret_cast<uint16_t*>(base) + total + elems : nullptr;
+}
+
 // The weight gradients of a backward chain (dWhh, d[Wg|Wm]) are sums over levels: each level's term is enqueued on a
 // stream beside the chain as soon as that level's d gh / d gm is final, where it fills the matrix-unit time the
 // latency-bound level kernels leave idle, instead of as whole-pass products after the chain with nothing beside them
@@ -593,6 +610,7 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
                                         Hp, w.ghn[k], nB, Hp, s));
         return DVAE_OK;
     };
+    const bool hg = half_gates(d, B);
     // One level of one direction of the DVAE chain: GRU (hidden product + pointwise), then the
     // gate/mapper product whose pointwise tail also gathers the next level's predecessor sum.
     auto level = [&](int k, int step, hipStream_t s) -> int {
@@ -601,32 +619,37 @@ extern "C" int dvae_encode_forward(const dvae_model_desc* m, const dvae_batch_co
         const int v = k == 0 ? step : n - 1 - step;
         const long r0 = (long)v * B;
         float* agg = w.agg[k] + r0 * Hp;
-        float* gates = w.gates[k] + r0 * 3 * Hp;
+        float* gates = hoff(w.gates[k], r0 * 3 * Hp, hg);
+        float* ghn = hoff(w.ghn[k], r0 * Hp, hg);
+        uint16_t* pre_gh = pre_of(w.gates[k], (size_t)nB * 3 * Hp, r0 * 3 * Hp, hg);
         // bf16 shadows (act_shadows; unfused path only -- the fused level kernels read fp32): this level's rows
         uint16_t* hs_h = (w.hs_h[k] && !fused) ? w.hs_h[k] + r0 * Hp : nullptr;
         uint16_t* agg_h = (w.agg_h[k] && !fused) ? w.agg_h[k] + r0 * Hp : nullptr;
         if (step == 0) {  // no predecessors yet: h_prev = 0, hidden product = 0 (one launch; leaves agg = 0 for the backward)
-            DVAE_TRY(gru_first_level(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, w.hs[k] + r0 * Hp,
-                                     w.ghn[k] + r0 * Hp, B, Hp, s, hs_h));
+            DVAE_TRY(gru_first_level(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, w.hs[k] + r0 * Hp, ghn, B, Hp, s,
+                                     hs_h, hg));
         } else if (!fused) {
-            DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s, 0, agg_h));
+            DVAE_TRY(lin_fwd(agg, Hp, nullptr, pw + L.whh[k], Hp, nullptr, hg ? reinterpret_cast<float*>(pre_gh) : gates, 3 * Hp, B,
+                             3 * Hp, Hp, 0, 0, s, hg, agg_h));
         }
         if (fused && step > 0)  // hidden product + GRU tail in one launch (chain.hip)
             DVAE_TRY(dvae_gru_level_fwd(agg, Hp, pw + L.whh[k], pw + L.gi[k], bv.types + r0, pw + L.bhn[k], gates,
                                         w.ghn[k] + r0 * Hp, w.hs[k] + r0 * Hp, Hp, B, Hp, s));
         else if (step > 0)
-            DVAE_TRY(gru_pointwise_fwd_h(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp, w.hs[k] + r0 * Hp, Hp,
-                                         w.ghn[k] + r0 * Hp, B, Hp, hs_h, s));
+            DVAE_TRY(gru_pointwise_fwd_h(gates, pw + L.gi[k], bv.types + r0, pw + L.bhn[k], agg, Hp, w.hs[k] + r0 * Hp, Hp, ghn,
+                                         B, Hp, hs_h, s, pre_gh));
         if (step < n - 1) {
             const long r1 = (long)(k == 0 ? v + 1 : v - 1) * B;
-            float* gm = w.gm[k] + r0 * 2 * Hp;
+            float* gm = hoff(w.gm[k], r0 * 2 * Hp, hg);
+            uint16_t* pre_gm = pre_of(w.gm[k], (size_t)nB * 2 * Hp, r0 * 2 * Hp, hg);
             if (fused) {  // gate/mapper product + its tail + the next level's predecessor sum
                 DVAE_TRY(dvae_gated_level_fwd(w.hs[k] + r0 * Hp, Hp, pw + L.wgm[k], pw + L.gv[k] + (size_t)v * 2 * Hp, gm,
                                               w.msg[k], Hp, (int)r0, w.agg[k] + r1 * Hp, Hp, off + r1, idx, B, Hp, s));
             } else {
-                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s, 0, hs_h));
+                DVAE_TRY(lin_fwd(w.hs[k] + r0 * Hp, Hp, nullptr, pw + L.wgm[k], Hp, nullptr, hg ? reinterpret_cast<float*>(pre_gm) : gm,
+                                 2 * Hp, B, 2 * Hp, Hp, 0, 0, s, hg, hs_h));
                 DVAE_TRY(gated_fwd_gather_h(gm, pw + L.gv[k] + (size_t)v * 2 * Hp, w.msg[k], Hp, (int)r0, w.agg[k] + r1 * Hp, Hp,
-                                            off + r1, idx, B, Hp, w.agg_h[k] ? w.agg_h[k] + r1 * Hp : nullptr, s));
+                                            off + r1, idx, B, Hp, w.agg_h[k] ? w.agg_h[k] + r1 * Hp : nullptr, s, pre_gm));
             }
         }
         return DVAE_OK;
@@ -806,12 +829,13 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         const int v = k == 0 ? step : n - 1 - step;
         const long r0 = (long)v * B;
         float* dhs = w.dhs[k] + r0 * Hp;
+        const bool hg = half_gates(d, B);  // (false whenever `fused`)
         // bf16 shadows of this level's d gm / d gh (act_shadows; unfused path)
         uint16_t* dgm_h = (w.dgm_h[k] && !fused) ? w.dgm_h[k] + r0 * 2 * Hp : nullptr;
         uint16_t* dgh_h = (w.dgh_h[k] && !fused) ? w.dgh_h[k] + r0 * 3 * Hp : nullptr;
         if (step < n - 1 && !fused) {
-            DVAE_TRY(gated_bwd_gather_h(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr, w.gm[k] + r0 * 2 * Hp,
-                                        w.dgm[k] + r0 * 2 * Hp, B, Hp, dgm_h, s));
+            DVAE_TRY(gated_bwd_gather_h(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr, hoff(w.gm[k], r0 * 2 * Hp, hg),
+                                        w.dgm[k] + r0 * 2 * Hp, B, Hp, dgm_h, s, hg));
             DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
                                dgm_h));
         }
@@ -821,9 +845,9 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                                         w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
         else
-            DVAE_TRY(gru_pointwise_bwd_h(dhs, Hp, w.gates[k] + r0 * 3 * Hp, w.ghn[k] + r0 * Hp, w.agg[k] + r0 * Hp, Hp,
-                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
-                                         step > 0 ? dgh_h : nullptr, s));
+            DVAE_TRY(gru_pointwise_bwd_h(dhs, Hp, hoff(w.gates[k], r0 * 3 * Hp, hg), hoff(w.ghn[k], r0 * Hp, hg), w.agg[k] + r0 * Hp,
+                                         Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
+                                         step > 0 ? dgh_h : nullptr, s, hg));
         if (step > 0 && fused) {
             // d agg += d gh W_hh, then -- same launch -- the gate/mapper pointwise backward of the level
             // processed next, whose d msg gathers d agg rows of this level (registers) and finished ones
@@ -991,6 +1015,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
     const bool fused = chain_fused(d, c->B);
     const bool tiny = loss_fwd_tiny(d, *c);  // the decoder's chain as one persistent launch
+    const bool hg = half_gates(d, c->B);     // (false whenever fused / tiny)
+    const size_t NG = (size_t)(nB + PT) * 3 * Hp, NM = (size_t)nB * 2 * Hp;  // elements of the gates / gm allocations
     if (tiny) {
         TinyChainArgs a = {};
         tiny_dir_fwd(a.d[0], w.agg, w.gates, w.ghn, w.st, w.gm, w.msg, whh, pw + L.wgm[0], gi, bhn, pw + L.gv[0],
@@ -1004,8 +1030,9 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     } else if (fused) {
         DVAE_TRY(dvae_gru_level_fwd(w.agg, Hp, whh, gi, bv.types, bhn, w.gates, w.ghn, w.st, Hp, B, Hp, s));
     } else {
-        DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, w.gates, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s));
-        DVAE_TRY(gru_pointwise_fwd_h(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, w.st_h, s));
+        DVAE_TRY(lin_fwd(w.agg, Hp, nullptr, whh, Hp, nullptr, hg ? reinterpret_cast<float*>(pre_of(w.gates, NG, 0, hg)) : w.gates,
+                         3 * Hp, B, 3 * Hp, Hp, 0, 0, s, hg));
+        DVAE_TRY(gru_pointwise_fwd_h(w.gates, gi, bv.types, bhn, w.agg, Hp, w.st, Hp, w.ghn, B, Hp, w.st_h, s, pre_of(w.gates, NG, 0, hg)));
     }
     // bf16 shadows of the states and predecessor sums (act_shadows; the unfused path writes and reads them)
     uint16_t* const st_h = (!tiny && !fused) ? w.st_h : nullptr;
@@ -1028,10 +1055,13 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                 DVAE_TRY(dvae_gru_level_fwd(w.agg + r0 * Hp, Hp, whh, gi, bv.types + r0, bhn, w.gates + r0 * 3 * Hp,
                                             w.ghn + r0 * Hp, w.st + r0 * Hp, Hp, B, Hp, s));
             } else if (v > 0) {
-                DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s,
-                                 0, agg_h ? agg_h + r0 * Hp : nullptr));
-                DVAE_TRY(gru_pointwise_fwd_h(w.gates + r0 * 3 * Hp, gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp, w.st + r0 * Hp, Hp,
-                                             w.ghn + r0 * Hp, B, Hp, st_h ? st_h + r0 * Hp : nullptr, s));
+                uint16_t* pre_gh = pre_of(w.gates, NG, r0 * 3 * Hp, hg);
+                DVAE_TRY(lin_fwd(w.agg + r0 * Hp, Hp, nullptr, whh, Hp, nullptr,
+                                 hg ? reinterpret_cast<float*>(pre_gh) : w.gates + r0 * 3 * Hp, 3 * Hp, B, 3 * Hp, Hp, 0, 0, s, hg,
+                                 agg_h ? agg_h + r0 * Hp : nullptr));
+                DVAE_TRY(gru_pointwise_fwd_h(hoff(w.gates, r0 * 3 * Hp, hg), gi, bv.types + r0, bhn, w.agg + r0 * Hp, Hp,
+                                             w.st + r0 * Hp, Hp, hoff(w.ghn, r0 * Hp, hg), B, Hp, st_h ? st_h + r0 * Hp : nullptr, s,
+                                             pre_gh));
             }
             if (by_level && v < n - 1) {
                 // The state of level v is final: its rows of the EA table and its vertex-type rows
@@ -1047,28 +1077,30 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
                                  Hp, 1, 0, s2));
             }
             if (v < n - 1) {
-                float* gm = w.gm + r0 * 2 * Hp;
+                float* gm = hoff(w.gm, r0 * 2 * Hp, hg);
+                uint16_t* pre_gm = pre_of(w.gm, NM, r0 * 2 * Hp, hg);
                 if (fused) {
                     DVAE_TRY(dvae_gated_level_fwd(w.st + r0 * Hp, Hp, pw + L.wgm[0], pw + L.gv[0] + (size_t)v * 2 * Hp, gm,
                                                   w.msg, Hp, (int)r0, w.agg + (r0 + B) * Hp, Hp, bv.pred_off + r0 + B,
                                                   bv.pred_idx, B, Hp, s));
                 } else {
-                    DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, gm, 2 * Hp, B, 2 * Hp, Hp, 0, 0, s, 0,
-                                     st_h ? st_h + r0 * Hp : nullptr));
+                    DVAE_TRY(lin_fwd(w.st + r0 * Hp, Hp, nullptr, pw + L.wgm[0], Hp, nullptr, hg ? reinterpret_cast<float*>(pre_gm) : gm,
+                                     2 * Hp, B, 2 * Hp, Hp, 0, 0, s, hg, st_h ? st_h + r0 * Hp : nullptr));
                     // pointwise tail + predecessor sum of vertex v + 1
                     DVAE_TRY(gated_fwd_gather_h(gm, pw + L.gv[0] + (size_t)v * 2 * Hp, w.msg, Hp, (int)r0, w.agg + (r0 + B) * Hp,
                                                 Hp, bv.pred_off + r0 + B, bv.pred_idx, B, Hp,
-                                                agg_h ? agg_h + (r0 + B) * Hp : nullptr, s));
+                                                agg_h ? agg_h + (r0 + B) * Hp : nullptr, s, pre_gm));
                 }
             }
         }
         // partial states: non-recurrent, one batched pass
         const long p0 = nB;
         DVAE_TRY(gather_sum_h(w.agg + p0 * Hp, Hp, w.msg, Hp, bv.p_off, bv.p_idx, PT, Hp, 0, agg_h ? agg_h + p0 * Hp : nullptr, s));
-        DVAE_TRY(lin_fwd(w.agg + p0 * Hp, Hp, nullptr, whh, Hp, nullptr, w.gates + p0 * 3 * Hp, 3 * Hp, PT, 3 * Hp, Hp, 0, 0, s, 0,
-                         agg_h ? agg_h + p0 * Hp : nullptr));
-        DVAE_TRY(gru_pointwise_fwd_h(w.gates + p0 * 3 * Hp, gi, bv.p_type, bhn, w.agg + p0 * Hp, Hp, w.st + p0 * Hp, Hp,
-                                     w.ghn + p0 * Hp, PT, Hp, st_h ? st_h + p0 * Hp : nullptr, s));
+        uint16_t* pre_p = pre_of(w.gates, NG, p0 * 3 * Hp, hg);
+        DVAE_TRY(lin_fwd(w.agg + p0 * Hp, Hp, nullptr, whh, Hp, nullptr, hg ? reinterpret_cast<float*>(pre_p) : w.gates + p0 * 3 * Hp,
+                         3 * Hp, PT, 3 * Hp, Hp, 0, 0, s, hg, agg_h ? agg_h + p0 * Hp : nullptr));
+        DVAE_TRY(gru_pointwise_fwd_h(hoff(w.gates, p0 * 3 * Hp, hg), gi, bv.p_type, bhn, w.agg + p0 * Hp, Hp, w.st + p0 * Hp, Hp,
+                                     hoff(w.ghn, p0 * Hp, hg), PT, Hp, st_h ? st_h + p0 * Hp : nullptr, s, pre_p));
     }
     // The loss terms meet through tickets (loss_kernels.hip: loss_ticket): the pair kernel's and the CE kernel's
     // workgroups each draw one, the last writes out3 -- so the vertex-type predictor's tail can run on the side stream.
@@ -1201,9 +1233,10 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         // bf16 shadows of d gh / d gm (act_shadows; the unfused path writes and reads them)
         uint16_t* const dgh_h = !fused ? w.dgh_h : nullptr;
         uint16_t* const dgm_h = !fused ? w.dgm_h : nullptr;
-        DVAE_TRY(gru_pointwise_bwd_h(w.dst + p0 * Hp, Hp, w.gates + p0 * 3 * Hp, w.ghn + p0 * Hp, w.agg + p0 * Hp, Hp,
-                                     w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
-                                     dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, s));
+        const bool hg = half_gates(d, B);  // as dvae_loss_forward saved them (false whenever fused)
+        DVAE_TRY(gru_pointwise_bwd_h(w.dst + p0 * Hp, Hp, hoff(w.gates, p0 * 3 * Hp, hg), hoff(w.ghn, p0 * Hp, hg), w.agg + p0 * Hp,
+                                     Hp, w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
+                                     dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, s, hg));
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s, nullptr,
                            dgh_h ? dgh_h + p0 * 3 * Hp : nullptr));
         // (only the last vertex's rows of d gm are not written by the chain below)
@@ -1238,8 +1271,8 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             if (v < n - 1 && !fused) {
                 // d msg = consumers' d agg (successor slots + partial rows), used in registers
                 DVAE_TRY(gated_bwd_gather_h(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp, bv.pt_off + r0, bv.pt_idx,
-                                            w.gm + r0 * 2 * Hp, w.dgm + r0 * 2 * Hp, B, Hp,
-                                            dgm_h ? dgm_h + r0 * 2 * Hp : nullptr, s));
+                                            hoff(w.gm, r0 * 2 * Hp, hg), w.dgm + r0 * 2 * Hp, B, Hp,
+                                            dgm_h ? dgm_h + r0 * 2 * Hp : nullptr, s, hg));
                 DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
                                    dgm_h ? dgm_h + r0 * 2 * Hp : nullptr));
             }
@@ -1249,9 +1282,9 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                             w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp,
                                             w.dagg + r0 * Hp, Hp, B, Hp, s));
             else
-                DVAE_TRY(gru_pointwise_bwd_h(dst, Hp, w.gates + r0 * 3 * Hp, w.ghn + r0 * Hp, w.agg + r0 * Hp, Hp, w.dgh + r0 * 3 * Hp,
-                                             w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
-                                             dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, s));
+                DVAE_TRY(gru_pointwise_bwd_h(dst, Hp, hoff(w.gates, r0 * 3 * Hp, hg), hoff(w.ghn, r0 * Hp, hg), w.agg + r0 * Hp, Hp,
+                                             w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
+                                             dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, s, hg));
             if (fused) {
                 dvae_level_desc da = {};
                 da.a = w.dgh + r0 * 3 * Hp; da.lda = 3 * Hp; da.K = 3 * Hp; da.w = whh;
