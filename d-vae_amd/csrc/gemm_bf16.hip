@@ -277,33 +277,33 @@ static int launch_cfg_h(GemmParams p, int akm, int bkm, hipStream_t s, int ah = 
         if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_, B_, G_, true>), grid, block, 0, s, p);  \
         else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_, B_, G_, false>), grid, block, 0, s, p);     \
     } while (0)
-    const bool vec = gemm_vec_epilogue_ok(p);
-    if constexpr (BM == 256) {  // built for the weight-gradient form only
-        if (!(akm && bkm)) return set_err(DVAE_ERR_ARG, "gemm: the 256 x 256 tile is built for two K-major operands");
-        // bf16-STORED operands (the edge predictor's gradient tables, the state shadow): A alone or both
+    // bf16-STORED K-major operands (weight-gradient form: the edge predictor's gradient tables, d gh / d gm and the
+    // state / predecessor-sum shadows): A alone or both
 #define DVAE_GEMM_LAUNCH_H(G_, BH_)                                                                                       \
     do {                                                                                                                  \
         if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, G_, true, true, BH_>), grid, block, 0, s, p);  \
         else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, G_, false, true, BH_>), grid, block, 0, s, p);     \
     } while (0)
-        if (bh && !ah) return set_err(DVAE_ERR_ARG, "gemm: a bf16-stored K-major B operand is built beside a bf16-stored A only");
-        if (ah) {
-            if (kg && bh) DVAE_GEMM_LAUNCH_H(true, true);
-            else if (kg) DVAE_GEMM_LAUNCH_H(true, false);
-            else if (bh) DVAE_GEMM_LAUNCH_H(false, true);
-            else DVAE_GEMM_LAUNCH_H(false, false);
-        } else
-#undef DVAE_GEMM_LAUNCH_H
+    const bool vec = gemm_vec_epilogue_ok(p);
+    if (bh && !ah) return set_err(DVAE_ERR_ARG, "gemm: a bf16-stored K-major B operand is built beside a bf16-stored A only");
+    if (ah) {
+        if (!(akm && bkm)) return set_err(DVAE_ERR_ARG, "gemm: bf16-stored operands here are K-major (the weight-gradient form)");
+        if (kg && bh) DVAE_GEMM_LAUNCH_H(true, true);
+        else if (kg) DVAE_GEMM_LAUNCH_H(true, false);
+        else if (bh) DVAE_GEMM_LAUNCH_H(false, true);
+        else DVAE_GEMM_LAUNCH_H(false, false);
+    } else
+    if constexpr (BM == 256) {  // built for the weight-gradient form only
+        if (!(akm && bkm)) return set_err(DVAE_ERR_ARG, "gemm: the 256 x 256 tile is built for two K-major operands");
         if (kg) DVAE_GEMM_LAUNCH(true, true, true);
         else DVAE_GEMM_LAUNCH(true, true, false);
     } else
-    if (ah || bh) return set_err(DVAE_ERR_ARG, "gemm: bf16-stored K-major operands are built for the 256 x 256 tile only");
-    else
     if (!akm && !bkm) DVAE_GEMM_LAUNCH(false, false, false);
     else if (!akm && bkm && !kg) DVAE_GEMM_LAUNCH(false, true, false);
     else if (akm && bkm && !kg) DVAE_GEMM_LAUNCH(true, true, false);
     else if (akm && bkm && kg) DVAE_GEMM_LAUNCH(true, true, true);
     else return set_err(DVAE_ERR_ARG, "gemm: this operand layout / gather combination is not built");
+#undef DVAE_GEMM_LAUNCH_H
 #undef DVAE_GEMM_LAUNCH
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
@@ -356,9 +356,10 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     if (!knob_256) use256 = false;
     if (knob_tile == 256) use256 = d.a_kmajor && d.b_kmajor && d.a_rows == nullptr;
     else if (knob_tile) use256 = false;
-    if (d.a_bf16) {  // bf16-stored K-major operands: this tile's loaders only, whatever the shape (a chunked product's tail)
+    if (d.a_bf16) {  // bf16-stored K-major operands (every tile's loaders take them)
         if (!can_split || d.a_rows) return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored K-major operands serve accumulating weight-gradient products only");
-        use256 = true;
+        if ((d.lda % 4 || (uintptr_t)d.A % 8) || (d.b_bf16 && (d.ldb % 4 || (uintptr_t)d.B % 8)))
+            return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored K-major operands need 8-byte aligned rows");
     }
     if (use256) {
         static const int cus = [] {
@@ -374,8 +375,6 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
         p.split_k = cdiv(d.K, p.k_per_split);
         if (knob_log)
             fprintf(stderr, "GEMMSELH 256x256 %d %d %d akm=1 bkm=1 split=%d br=%d\n", d.M, d.N, d.K, p.split_k, d.b_rows != nullptr);
-        if ((d.a_bf16 && (d.lda % 4 || (uintptr_t)d.A % 8)) || (d.b_bf16 && (d.ldb % 4 || (uintptr_t)d.B % 8)))
-            return set_err(DVAE_ERR_ARG, "gemm_bf16: bf16-stored K-major operands need 8-byte aligned rows");
         return launch_cfg_h<256, 256, 2, 4>(p, d.a_kmajor, d.b_kmajor, s, d.a_bf16, d.b_bf16);
     }
     if (knob_tile == 128) { use128 = true; small_m = false; }
@@ -406,9 +405,9 @@ int gemm_bf16(const dvae_gemm_desc& d, hipStream_t s) {
     if (knob_log)
         fprintf(stderr, "GEMMSELH %s %d %d %d akm=%d bkm=%d split=%d br=%d\n", small_m ? "32x128" : use128 ? "128x128" : "64x64", d.M,
                 d.N, d.K, d.a_kmajor, d.b_kmajor, p.split_k, d.b_rows != nullptr);
-    if (small_m) return launch_cfg_h<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s);
-    if (use128) return launch_cfg_h<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
-    return launch_cfg_h<64, 64, 2, 2>(p, d.a_kmajor, d.b_kmajor, s);
+    if (small_m) return launch_cfg_h<32, 128, 1, 4>(p, d.a_kmajor, d.b_kmajor, s, d.a_bf16, d.b_bf16);
+    if (use128) return launch_cfg_h<128, 128, 2, 2>(p, d.a_kmajor, d.b_kmajor, s, d.a_bf16, d.b_bf16);
+    return launch_cfg_h<64, 64, 2, 2>(p, d.a_kmajor, d.b_kmajor, s, d.a_bf16, d.b_bf16);
 }
 
 }  // namespace dvae

@@ -154,6 +154,8 @@ struct ColsumJobDesc {  // out[c] += scale * sum over rows of x[row][c]   (point
     int ld_x, rows, width, x_bf16;
 };
 int colsum_jobs(const ColsumJobDesc* jobs, int n, hipStream_t s);
+int type_colsum_h(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T, float* gi,
+                  float* bhn, int32_t rows, int32_t Hp, hipStream_t stream, int gh);
 int segment_colsum_h(float* out, int ld_out, const uint16_t* x, int ld_x, int rows, int seg_rows, int width, hipStream_t s);
 int reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float eps_scale, int training, float* z,
                     float* kld_sum, int B, int nz, int NZp, hipStream_t s, float* zero_a = nullptr, float* zero_b = nullptr,

@@ -182,10 +182,12 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const fl
     }
         GRUB(x) GRUB(y) GRUB(z) GRUB(w)
 #undef GRUB
-        float* o = dgh + (long)r * 3 * Hp;
-        st4(o + c, dR);
-        st4(o + Hp + c, dZ);
-        st4(o + 2 * Hp + c, dGN);
+        if (dgh) {  // (null: the bf16 copy below is the only one, train.hip half_grads())
+            float* o = dgh + (long)r * 3 * Hp;
+            st4(o + c, dR);
+            st4(o + Hp + c, dZ);
+            st4(o + 2 * Hp + c, dGN);
+        }
         if (dgh_h) {  // bf16 shadow of d gh: the A operand of the level's data-gradient product
             uint16_t* oh = dgh_h + (long)r * 3 * Hp;
             st4h(oh + c, dR);
@@ -290,9 +292,11 @@ __global__ void gated_bwd_gather_kernel(const float* __restrict__ dagg, int ld, 
         float4 dg = make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
                                 d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w));
         float4 dm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-        float* o = dgm + (long)r * 2 * Hp;
-        st4(o + c, dg);
-        st4(o + Hp + c, dm);
+        if (dgm) {  // (null: the bf16 copy below is the only one)
+            float* o = dgm + (long)r * 2 * Hp;
+            st4(o + c, dg);
+            st4(o + Hp + c, dm);
+        }
         if (dgm_h) {  // bf16 shadow of d gm: the A operand of the level's data-gradient product
             uint16_t* oh = dgm_h + (long)r * 2 * Hp;
             st4h(oh + c, dg);
@@ -433,6 +437,8 @@ __global__ __launch_bounds__(1024) void type_csr_kernel(const int* __restrict__ 
 //   bhn[0:Hp]      += sum over all rows of dgh[:, 2Hp:3Hp]          (d (W_hn h + b_hn))
 //   gi[t][2Hp:3Hp] += sum over rows of type t of dgin               (d pre_n)
 // grid (ceil(Hp / 64) column blocks of 64 float4, row chunks, T); partial sums are added with atomics.
+// GH: dgh points at bf16 words (the backward tails' bf16-only d gh: train.hip half_grads()); dgin stays fp32
+template <bool GH>
 __global__ __launch_bounds__(256) void type_colsum_kernel(const float* __restrict__ dgh, const float* __restrict__ dgin,
                                                           const int* __restrict__ off, const int* __restrict__ idx,
                                                           float* __restrict__ gi, float* __restrict__ bhn, int Hp,
@@ -446,18 +452,23 @@ __global__ __launch_bounds__(256) void type_colsum_kernel(const float* __restric
     const int c4 = blockIdx.x * 64 + tx;  // float4 column of the 4Hp-wide virtual row
     const bool on = c4 < Hp;
     const int col = c4 * 4;
-    const float* base = col < 3 * Hp ? dgh + col : dgin + (col - 3 * Hp);
-    const long ld = col < 3 * Hp ? 3 * Hp : Hp;
+    const bool in_gh = col < 3 * Hp;
+    const long ld = in_gh ? 3 * Hp : Hp;
+    const long c0 = in_gh ? col : col - 3 * Hp;
+    auto row = [&](int r) -> float4 {
+        if (GH && in_gh) return ldg4<true>(dgh, c0 + r * ld);
+        return ld4((in_gh ? dgh : dgin) + c0 + r * ld);
+    };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (on) {
         float4 a1 = acc, a2 = acc, a3 = acc;
         int k = k0 + ty;
         for (; k + 12 < k1; k += 16) {  // four independent row streams per thread
-            float4 v0 = ld4(base + idx[k] * ld), v1 = ld4(base + idx[k + 4] * ld);
-            float4 v2 = ld4(base + idx[k + 8] * ld), v3 = ld4(base + idx[k + 12] * ld);
+            float4 v0 = row(idx[k]), v1 = row(idx[k + 4]);
+            float4 v2 = row(idx[k + 8]), v3 = row(idx[k + 12]);
             acc = add4(acc, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
         }
-        for (; k < k1; k += 4) acc = add4(acc, ld4(base + idx[k] * ld));
+        for (; k < k1; k += 4) acc = add4(acc, row(idx[k]));
         acc = add4(add4(acc, a1), add4(a2, a3));
     }
     red[ty][tx] = acc;
@@ -565,7 +576,7 @@ int gru_pointwise_bwd_h(const float* dh, int ld_dh, const float* gates, const fl
                         float* dgh, float* dgin, float* dhprev, int ld_dhprev, int rows, int Hp, uint16_t* dgh_h, hipStream_t s,
                         int hg) {
     if (rows == 0) return DVAE_OK;
-    DVAE_REQUIRE(dh && gates && ghn && dgh && dgin, "gru_pointwise_bwd: null pointer");
+    DVAE_REQUIRE(dh && gates && ghn && (dgh || dgh_h) && dgin, "gru_pointwise_bwd: null pointer");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld_dh % 4 == 0, "gru_pointwise_bwd: bad Hp/ld");
     long total = (long)rows * (Hp / 4);
     if (hg)
@@ -645,7 +656,7 @@ namespace dvae {
 int gated_bwd_gather_h(const float* dagg, int ld, const int* off, const int* idx, const float* dagg2, const int* off2,
                        const int* idx2, const float* gm, float* dgm, int rows, int Hp, uint16_t* dgm_h, hipStream_t s, int hg) {
     if (rows == 0) return DVAE_OK;
-    DVAE_REQUIRE(dagg && off && idx && gm && dgm, "gated_bwd_gather: null pointer");
+    DVAE_REQUIRE(dagg && off && idx && gm && (dgm || dgm_h), "gated_bwd_gather: null pointer");
     DVAE_REQUIRE(!off2 || (dagg2 && idx2), "gated_bwd_gather: second list incomplete");
     DVAE_REQUIRE(Hp > 0 && Hp % 4 == 0 && ld % 4 == 0, "gated_bwd_gather: bad size");
     long total = (long)rows * (Hp / 4);
@@ -676,6 +687,11 @@ extern "C" int dvae_type_csr(const int32_t* types_a, int32_t na, const int32_t* 
 
 extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T,
                                 float* gi, float* bhn, int32_t rows, int32_t Hp, void* stream) {
+    return dvae::type_colsum_h(dgh, dgin, off, idx, T, gi, bhn, rows, Hp, (hipStream_t)stream, 0);
+}
+// gh: dgh points at bf16 words
+int dvae::type_colsum_h(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T, float* gi,
+                        float* bhn, int32_t rows, int32_t Hp, hipStream_t stream, int gh) {
     if (rows == 0) return DVAE_OK;
     DVAE_REQUIRE(dgh && dgin && off && idx && gi && bhn, "type_colsum: null pointer");
     DVAE_REQUIRE(T >= 1 && T <= 32 && Hp > 0 && Hp % 4 == 0, "type_colsum: bad sizes (T=%d Hp=%d)", T, Hp);
@@ -685,8 +701,12 @@ extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32
     long rpc = ((long)rows * T * xblocks + 16383) / 16384;
     if (rpc < 128) rpc = 128;  // (cfg 2, 8192 rows: 32 / 64 / 128 / 256 rows per chunk -> 37 / 22 / 18.5 / 28 us)
     const int chunks = cdiv(rows, rpc);
-    hipLaunchKernelGGL(type_colsum_kernel, dim3(xblocks, chunks, T), dim3(256), 0, (hipStream_t)stream, dgh, dgin, off, idx,
-                       gi, bhn, Hp, (int)rpc);
+    if (gh)
+        hipLaunchKernelGGL(type_colsum_kernel<true>, dim3(xblocks, chunks, T), dim3(256), 0, stream, dgh, dgin, off, idx, gi, bhn,
+                           Hp, (int)rpc);
+    else
+        hipLaunchKernelGGL(type_colsum_kernel<false>, dim3(xblocks, chunks, T), dim3(256), 0, stream, dgh, dgin, off, idx, gi, bhn,
+                           Hp, (int)rpc);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }

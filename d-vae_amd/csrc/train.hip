@@ -391,26 +391,33 @@ static int check_batch(const Dims& d, const dvae_batch_counts* c) {
 
 // weight gradients shared by every GRU pass: dWhh over the rows [lo, hi) (the passes call it level by level, as soon
 // as a level's d gh is final, on a stream beside the chain), and d gi_tab, d bhn over all rows at the end
+// dgh_h / agg_h (half_grads(): d gh exists as bf16 only; nullable together): the bf16-stored operands
 static int gru_whh_wgrad(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* agg,
-                         long lo, long hi, hipStream_t s, int max_split = 0) {
+                         long lo, long hi, hipStream_t s, int max_split = 0, const uint16_t* dgh_h = nullptr,
+                         const uint16_t* agg_h = nullptr) {
     const int Hp = d.Hp;
     if (hi <= lo) return DVAE_OK;
     return lin_wgrad(dgh + (size_t)lo * 3 * Hp, 3 * Hp, agg + (size_t)lo * Hp, Hp, nullptr, pg + L.whh[g], Hp, (int)(hi - lo),
-                     3 * Hp, Hp, s, 0, max_split);
+                     3 * Hp, Hp, s, 0, max_split, dgh_h ? dgh_h + (size_t)lo * 3 * Hp : nullptr,
+                     (dgh_h && agg_h) ? agg_h + (size_t)lo * Hp : nullptr);
 }
 static int gru_type_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
-                           const float* xoh, int rows, hipStream_t s) {
+                           const float* xoh, int rows, hipStream_t s, const uint16_t* dgh_h = nullptr) {
     // d gi_tab[t] = sum_{rows of type t}: (d pre_r, d pre_z) from dgh, d pre_n from dgin; d bhn = column sum of
     // dgh's n block: one sweep over the rows sorted by type (instead of two one-hot products and a column sum)
     const int* tcsr = reinterpret_cast<const int*>(xoh);
+    if (dgh_h)
+        return type_colsum_h(reinterpret_cast<const float*>(dgh_h), dgin, tcsr, tcsr + 40, d.T, pg + L.gi[g], pg + L.bhn[g], rows,
+                             d.Hp, s, 1);
     return dvae_type_colsum(dgh, dgin, tcsr, tcsr + 40, d.T, pg + L.gi[g], pg + L.bhn[g], rows, d.Hp, s);
 }
 // (rows [zero_lo, zero_hi) have h_prev = 0 -- the first level of an encoder pass -- and are left out of dWhh)
 static int gru_wgrads(const Dims& d, const PackedLayout& L, int g, float* pg, const float* dgh, const float* dgin,
-                      const float* agg, const float* xoh, int rows, hipStream_t s, int zero_lo = 0, int zero_hi = 0) {
+                      const float* agg, const float* xoh, int rows, hipStream_t s, int zero_lo = 0, int zero_hi = 0,
+                      const uint16_t* dgh_h = nullptr, const uint16_t* agg_h = nullptr) {
     const int lo = zero_lo == 0 ? zero_hi : 0, hi = zero_hi == rows && zero_lo > 0 ? zero_lo : rows;  // a prefix or a suffix
-    DVAE_TRY(gru_whh_wgrad(d, L, g, pg, dgh, agg, lo, hi, s));
-    return gru_type_wgrads(d, L, g, pg, dgh, dgin, xoh, rows, s);
+    DVAE_TRY(gru_whh_wgrad(d, L, g, pg, dgh, agg, lo, hi, s, 0, dgh_h, agg_h));
+    return gru_type_wgrads(d, L, g, pg, dgh, dgin, xoh, rows, s, dgh_h);
 }
 
 }  // namespace dvae
@@ -507,6 +514,14 @@ static bool chain_fused_bwd(const Dims& d, int B) {
 static bool half_gates(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_GATES_BF16"); return v ? atoi(v) : 1; }();
     return knob && act_shadows(d, B) && bf16_weight_copies_on() && !chain_fused(d, B) && !chain_fused_bwd(d, B);
+}
+// HALF GRADS (on top of half gates; DVAE_GRADS_BF16=0: off): d gh / d gm exist ONLY as the bf16 arrays that were their
+// shadows -- the weight-gradient products rounded them to bf16 on the way to LDS anyway (now: gemm_bf16.hip's bf16-stored
+// K-major loaders, with the state / predecessor-sum shadows on the other side), the data gradients already read the
+// shadows, and the per-type / per-level column sums read bf16 (type_colsum_kernel<true>, segment_colsum_kernel<true>).
+static bool half_grads(const Dims& d, int B) {
+    static const int knob = [] { const char* v = getenv("DVAE_GRADS_BF16"); return v ? atoi(v) : 1; }();
+    return knob && half_gates(d, B);
 }
 static inline float* hoff(float* base, size_t elems, bool hg) {
     return hg ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + elems) : base + elems;
@@ -808,6 +823,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         // message (the last vertex of the pass): only those rows need the zeros
         if (!d.bn)
             DVAE_HIP(hipMemsetAsync(w.dgm[k] + (size_t)(k == 0 ? n - 1 : 0) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
+        if (!d.bn && half_grads(d, B))
+            DVAE_HIP(hipMemsetAsync(w.dgm_h[k] + (size_t)(k == 0 ? n - 1 : 0) * B * 2 * Hp, 0, sizeof(uint16_t) * (size_t)B * 2 * Hp, s));
         return DVAE_OK;
     };
     auto run_dir_bn = [&](int k, hipStream_t s) -> int {
@@ -830,14 +847,15 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         const long r0 = (long)v * B;
         float* dhs = w.dhs[k] + r0 * Hp;
         const bool hg = half_gates(d, B);  // (false whenever `fused`)
+        const bool gh = half_grads(d, B);
         // bf16 shadows of this level's d gm / d gh (act_shadows; unfused path)
         uint16_t* dgm_h = (w.dgm_h[k] && !fused) ? w.dgm_h[k] + r0 * 2 * Hp : nullptr;
         uint16_t* dgh_h = (w.dgh_h[k] && !fused) ? w.dgh_h[k] + r0 * 3 * Hp : nullptr;
         if (step < n - 1 && !fused) {
             DVAE_TRY(gated_bwd_gather_h(w.dagg[k], Hp, toff + r0, tidx, nullptr, nullptr, nullptr, hoff(w.gm[k], r0 * 2 * Hp, hg),
-                                        w.dgm[k] + r0 * 2 * Hp, B, Hp, dgm_h, s, hg));
+                                        gh ? nullptr : w.dgm[k] + r0 * 2 * Hp, B, Hp, dgm_h, s, hg));
             DVAE_TRY(lin_dgrad(w.dgm[k] + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[k], Hp, dhs, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
-                               dgm_h));
+                               dgm_h, gh));
         }
         // (fused: d gm of this level was written by the tail of the previous level's dgrad kernel, below)
         if (fused && step < n - 1)  // d h += d gm [Wg | Wm] and the GRU pointwise backward in one launch (chain.hip)
@@ -846,8 +864,8 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
         else
             DVAE_TRY(gru_pointwise_bwd_h(dhs, Hp, hoff(w.gates[k], r0 * 3 * Hp, hg), hoff(w.ghn[k], r0 * Hp, hg), w.agg[k] + r0 * Hp,
-                                         Hp, w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
-                                         step > 0 ? dgh_h : nullptr, s, hg));
+                                         Hp, gh ? nullptr : w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
+                                         (step > 0 || gh) ? dgh_h : nullptr, s, hg));
         if (step > 0 && fused) {
             // d agg += d gh W_hh, then -- same launch -- the gate/mapper pointwise backward of the level
             // processed next, whose d msg gathers d agg rows of this level (registers) and finished ones
@@ -860,18 +878,20 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
             DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
         } else if (step > 0)
             DVAE_TRY(lin_dgrad(w.dgh[k] + r0 * 3 * Hp, 3 * Hp, pw + L.whh[k], Hp, w.dagg[k] + r0 * Hp, Hp, nullptr, B,
-                               3 * Hp, Hp, 1, s, nullptr, dgh_h));
+                               3 * Hp, Hp, 1, s, nullptr, dgh_h, gh));
         if (wbl) {
             // final now: d gh of this level; d gm of the level processed next (fused: the tail above) or of this one
             if (dirs == 2) DVAE_TRY(aux_after(side_guard, s));
             else DVAE_TRY(fork_side(side_guard));
             if (step > 0)  // (the pass's first level has h_prev = 0: no term)
-                DVAE_TRY(gru_whh_wgrad(d, L, k, pg, w.dgh[k], w.agg[k], r0, r0 + B, wg_stream, wbl_split()));
+                DVAE_TRY(gru_whh_wgrad(d, L, k, pg, w.dgh[k], w.agg[k], r0, r0 + B, wg_stream, wbl_split(), gh ? w.dgh_h[k] : nullptr,
+                                       w.agg_h[k]));
             const int sg = fused ? step - 1 : step;  // forward-pass step of the level whose d gm is final
             if (sg >= 0 && sg < n - 1) {
                 const long rg = (long)(k == 0 ? sg : n - 1 - sg) * B;
                 DVAE_TRY(lin_wgrad(w.dgm[k] + rg * 2 * Hp, 2 * Hp, w.hs[k] + rg * Hp, Hp, nullptr, pg + L.wgm[k], Hp, B,
-                                   2 * Hp, Hp, wg_stream, 0, wbl_split()));
+                                   2 * Hp, Hp, wg_stream, 0, wbl_split(), gh ? w.dgm_h[k] + rg * 2 * Hp : nullptr,
+                                   gh ? w.hs_h[k] + rg * Hp : nullptr));
             }
         }
         return DVAE_OK;
@@ -880,15 +900,18 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
         if (!d.bn) {
             // (d gm of the pass's last vertex is zero -- no message leaves it: those B rows are left out)
             const size_t o = k == 0 ? 0 : (size_t)B;
+            const bool gh = half_grads(d, B);
             if (!wbl)
                 DVAE_TRY(lin_wgrad(w.dgm[k] + o * 2 * Hp, 2 * Hp, w.hs[k] + o * Hp, Hp, nullptr, pg + L.wgm[k], Hp, nB - B,
-                                   2 * Hp, Hp, s));
-            DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
+                                   2 * Hp, Hp, s, 0, 0, gh ? w.dgm_h[k] + o * 2 * Hp : nullptr, gh ? w.hs_h[k] + o * Hp : nullptr));
+            if (gh) DVAE_TRY(segment_colsum_h(pg + L.gv[k], 2 * Hp, w.dgm_h[k], 2 * Hp, nB, B, 2 * Hp, s));
+            else DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[k], 2 * Hp, w.dgm[k], 2 * Hp, nB, B, 2 * Hp, s));
         }
-        if (wbl) return gru_type_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.xoh, nB, s);
+        const uint16_t* dgh_only = half_grads(d, B) ? w.dgh_h[k] : nullptr;
+        if (wbl) return gru_type_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.xoh, nB, s, dgh_only);
         // DVAE: the pass's first level (vertex 0 forward, vertex n-1 backward) has no predecessors, h_prev = 0
         const int z_lo = d.bn ? 0 : (k == 0 ? 0 : nB - B), z_hi = d.bn ? 0 : (k == 0 ? B : nB);
-        DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s, z_lo, z_hi));
+        DVAE_TRY(gru_wgrads(d, L, k, pg, w.dgh[k], w.dgin[k], w.agg[k], w.xoh, nB, s, z_lo, z_hi, dgh_only, w.agg_h[k]));
         return DVAE_OK;
     };
     // as in the forward pass: two streams, enqueued level by level in turn
@@ -1013,6 +1036,8 @@ extern "C" int dvae_loss_forward(const dvae_model_desc* m, const dvae_batch_coun
     }
     // H0 = tanh(fc3 z) lives in the level-0 rows of agg: it is h_prev of vertex 0 (models.py:810-814)
     DVAE_TRY(lin_fwd(w.z, d.NZp, nullptr, pw + L.fc3, d.NZp, pw + L.b3, w.agg, Hp, B, Hp, d.NZp, 2, 0, s));
+    // (half grads: the backward's d W_hh product reads the predecessor-sum shadow of every row, level 0 = H0 included)
+    if (half_grads(d, c->B)) DVAE_TRY(dvae_f32_to_bf16(w.agg, w.agg_h, (int64_t)B * Hp, s));
     const bool fused = chain_fused(d, c->B);
     const bool tiny = loss_fwd_tiny(d, *c);  // the decoder's chain as one persistent launch
     const bool hg = half_gates(d, c->B);     // (false whenever fused / tiny)
@@ -1234,13 +1259,19 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         uint16_t* const dgh_h = !fused ? w.dgh_h : nullptr;
         uint16_t* const dgm_h = !fused ? w.dgm_h : nullptr;
         const bool hg = half_gates(d, B);  // as dvae_loss_forward saved them (false whenever fused)
+        const bool gh = half_grads(d, B);  // d gh / d gm as bf16 only
         DVAE_TRY(gru_pointwise_bwd_h(w.dst + p0 * Hp, Hp, hoff(w.gates, p0 * 3 * Hp, hg), hoff(w.ghn, p0 * Hp, hg), w.agg + p0 * Hp,
-                                     Hp, w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
+                                     Hp, gh ? nullptr : w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
                                      dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, s, hg));
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s, nullptr,
-                           dgh_h ? dgh_h + p0 * 3 * Hp : nullptr));
+                           dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, gh));
         // (only the last vertex's rows of d gm are not written by the chain below)
         DVAE_HIP(hipMemsetAsync(w.dgm + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(float) * (size_t)B * 2 * Hp, s));
+        if (gh) DVAE_HIP(hipMemsetAsync(w.dgm_h + (size_t)(n - 1) * B * 2 * Hp, 0, sizeof(uint16_t) * (size_t)B * 2 * Hp, s));
+        const uint16_t* const dgh_only = gh ? w.dgh_h : nullptr;
+        const uint16_t* const dgm_only = gh ? w.dgm_h : nullptr;
+        const uint16_t* const agg_sh = gh ? w.agg_h : nullptr;  // (level 0: converted by dvae_loss_forward)
+        const uint16_t* const st_sh = gh ? w.st_h : nullptr;
         const bool tiny = fused && chain_tiny_persist(d, B);  // the reverse chain as one persistent launch
         const bool wbl = !tiny && wgrad_by_level() && wbl_size_ok(d, B);
         hipStream_t s2 = side->stream;
@@ -1261,7 +1292,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         }
         if (wbl) {  // the partial rows' d gh is final: their term of dWhh starts the side stream's run beside the chain
             DVAE_TRY(fork_side(side_guard));
-            DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2));
+            DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, p0, NST, s2, 0, dgh_only, agg_sh));
         }
         int pend_h = 0, pend_g = 0;  // finished levels whose weight-gradient terms are not issued yet (wbl_group)
         long lo_g = 0;
@@ -1271,10 +1302,10 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
             if (v < n - 1 && !fused) {
                 // d msg = consumers' d agg (successor slots + partial rows), used in registers
                 DVAE_TRY(gated_bwd_gather_h(w.dagg, Hp, bv.succ_off + r0, bv.succ_idx, w.dagg + p0 * Hp, bv.pt_off + r0, bv.pt_idx,
-                                            hoff(w.gm, r0 * 2 * Hp, hg), w.dgm + r0 * 2 * Hp, B, Hp,
+                                            hoff(w.gm, r0 * 2 * Hp, hg), gh ? nullptr : w.dgm + r0 * 2 * Hp, B, Hp,
                                             dgm_h ? dgm_h + r0 * 2 * Hp : nullptr, s, hg));
                 DVAE_TRY(lin_dgrad(w.dgm + r0 * 2 * Hp, 2 * Hp, pw + L.wgm[0], Hp, dst, Hp, nullptr, B, 2 * Hp, Hp, 1, s, nullptr,
-                                   dgm_h ? dgm_h + r0 * 2 * Hp : nullptr));
+                                   dgm_h ? dgm_h + r0 * 2 * Hp : nullptr, gh));
             }
             // (fused: d gm of vertex v was written by the tail of vertex v + 1's dgrad kernel, below)
             if (fused && v < n - 1)
@@ -1283,7 +1314,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                             w.dagg + r0 * Hp, Hp, B, Hp, s));
             else
                 DVAE_TRY(gru_pointwise_bwd_h(dst, Hp, hoff(w.gates, r0 * 3 * Hp, hg), hoff(w.ghn, r0 * Hp, hg), w.agg + r0 * Hp, Hp,
-                                             w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
+                                             gh ? nullptr : w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
                                              dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, s, hg));
             if (fused) {
                 dvae_level_desc da = {};
@@ -1298,7 +1329,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                 DVAE_TRY(dvae_chain_level_batch(DVAE_LEVEL_DGRAD_ACC, &da, 1, B, Hp, s));
             } else
                 DVAE_TRY(lin_dgrad(w.dgh + r0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + r0 * Hp, Hp, nullptr, B, 3 * Hp, Hp, 1, s, nullptr,
-                                   dgh_h ? dgh_h + r0 * 3 * Hp : nullptr));
+                                   dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, gh));
             if (wbl) {
                 // final now: d gh of vertex v, and d gm of vertex v - 1 (fused: the tail above) or v (unfused: this iteration)
                 const int vg = fused ? v - 1 : v;
@@ -1309,10 +1340,12 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                 }
                 if (pend_h >= wbl_group() || v == 0) {
                     DVAE_TRY(fork_side(side_guard));
-                    DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + (long)pend_h * B, s2, wbl_split()));
+                    DVAE_TRY(gru_whh_wgrad(d, L, 2, pg, w.dgh, w.agg, r0, r0 + (long)pend_h * B, s2, wbl_split(), dgh_only, agg_sh));
                     if (pend_g > 0)
                         DVAE_TRY(lin_wgrad(w.dgm + (size_t)lo_g * B * 2 * Hp, 2 * Hp, w.st + (size_t)lo_g * B * Hp, Hp, nullptr,
-                                           pg + L.wgm[0], Hp, pend_g * B, 2 * Hp, Hp, s2, 0, wbl_split()));
+                                           pg + L.wgm[0], Hp, pend_g * B, 2 * Hp, Hp, s2, 0, wbl_split(),
+                                           dgm_only ? dgm_only + (size_t)lo_g * B * 2 * Hp : nullptr,
+                                           dgm_only ? st_sh + (size_t)lo_g * B * Hp : nullptr));
                     pend_h = pend_g = 0;
                 }
             }
@@ -1321,8 +1354,9 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     // the GRU's remaining weight gradients go to the side stream, behind the predictors' and the per-level terms
     DVAE_TRY(fork_side(side_guard));
     const bool wbl_done = !d.bn && wgrad_by_level() && wbl_size_ok(d, B) && !(fused && chain_tiny_persist(d, B));
-    if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream));
-    else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream));
+    const bool gh_all = !d.bn && half_grads(d, B);
+    if (wbl_done) DVAE_TRY(gru_type_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.xoh, NST, side->stream, gh_all ? w.dgh_h : nullptr));
+    else DVAE_TRY(gru_wgrads(d, L, 2, pg, w.dgh, w.dgin, w.agg, w.xoh, NST, side->stream, 0, 0, gh_all ? w.dgh_h : nullptr, w.agg_h));
     // ---- H0 = tanh(fc3 z), z = reparameterize(mu, logvar) ------------------------------
     EW(tanh_bwd_kernel, (long)B * Hp, w.dagg, w.agg, (long)B * Hp);
     DVAE_TRY(dvae_segment_colsum_f32(pg + L.b3, Hp, w.dagg, Hp, B, B, Hp, s));
@@ -1331,8 +1365,11 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
     DVAE_TRY(reparam_kld_bwd(mu, logvar, eps, eps_scale, training, w.dz, g_kld, dmu, dlogvar, B, d.nz, d.NZp, s));
     if (!d.bn) {
         // (d gm of the last vertex is zero: left out)
-        if (!wbl_done) DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s));
-        DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
+        if (!wbl_done)
+            DVAE_TRY(lin_wgrad(w.dgm, 2 * Hp, w.st, Hp, nullptr, pg + L.wgm[0], Hp, nB - B, 2 * Hp, Hp, s, 0, 0, gh_all ? w.dgm_h : nullptr,
+                               gh_all ? w.st_h : nullptr));
+        if (gh_all) DVAE_TRY(segment_colsum_h(pg + L.gv[0], 2 * Hp, w.dgm_h, 2 * Hp, nB, B, 2 * Hp, s));
+        else DVAE_TRY(dvae_segment_colsum_f32(pg + L.gv[0], 2 * Hp, w.dgm, 2 * Hp, nB, B, 2 * Hp, s));
     }
     DVAE_TRY(join_side(side_guard));
     return DVAE_OK;

@@ -44,15 +44,17 @@ def test_parity_with_fused_level_kernels_forced(extra):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("gates", ["0", "1"], ids=["fp32-gates", "half-gates"])
-def test_bf16_parity_with_activation_shadows_forced(gates):
+@pytest.mark.parametrize("extra", [{"DVAE_GATES_BF16": "0"}, {"DVAE_GATES_BF16": "1", "DVAE_GRADS_BF16": "0"}, {}],
+                         ids=["fp32-gates", "half-gates", "half-gates-and-grads"])
+def test_bf16_parity_with_activation_shadows_forced(extra):
     """bf16 mode above 256 graphs per batch, levels too large for the fused level kernels (cfg 5): the chains run as
     product + pointwise launches, states / predecessor sums / d gh / d gm get bf16 shadows that the products read
     (csrc/train.hip: act_shadows), and -- DVAE_GATES_BF16, default on -- the pre-activations and the saved gates are
-    stored as bf16 (half_gates).  The parity batches are smaller: DVAE_ACT_BF16=2 forces the shadows at every size and
+    stored as bf16 (half_gates) and d gh / d gm exist as bf16 only (half_grads, DVAE_GRADS_BF16, default on: bf16-stored
+    K-major operands on every weight-gradient tile, bf16 column sums).  The parity batches are smaller: DVAE_ACT_BF16=2 forces the shadows at every size and
     DVAE_CHAIN_FUSED*=0 keeps the small levels off the fused kernels (which would bypass both), and the bf16-mode
     parity cases must hold."""
-    env = dict(os.environ, DVAE_ACT_BF16="2", DVAE_CHAIN_FUSED="0", DVAE_CHAIN_FUSED_BWD="0", DVAE_GATES_BF16=gates)
+    env = dict(os.environ, DVAE_ACT_BF16="2", DVAE_CHAIN_FUSED="0", DVAE_CHAIN_FUSED_BWD="0", **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", "cfg5_shape_bf16_mode_close_to_oracle or bf16_mode_close_to_oracle", "-p", "no:cacheprovider",
                         "--timeout", "120", "--timeout-method", "thread"],

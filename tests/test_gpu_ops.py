@@ -704,12 +704,13 @@ def test_gemm_bf16_wgrad_splitk(rows, N, K):
     assert (out2 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
 
 
-@pytest.mark.parametrize("rows,N,K", [(16421, 1000, 1000), (20000, 2048, 1024)])
+@pytest.mark.parametrize("rows,N,K", [(16421, 1000, 1000), (20000, 2048, 1024), (8192, 1536, 512), (5000, 32, 1536), (70, 128, 512)])
 @pytest.mark.parametrize("b_half", [False, True])
 def test_gemm_bf16_wgrad_stored_kmajor(rows, N, K, b_half, span_limit):
-    """round 3: the large weight-gradient tile with a bf16-STORED K-major A (the edge predictor's gradient tables as the
-    pair backward writes them) and an fp32 or bf16-stored (gathered) B: identical to the same product of the rounded
-    operands held in fp32"""
+    """round 3: weight gradients with a bf16-STORED K-major A (the edge predictor's gradient tables as the pair backward
+    writes them, d gh / d gm as the backward tails write them) and an fp32 or bf16-stored (gathered) B, on every tile of
+    gemm_bf16.hip (256 x 256 for the first two shapes, 128 x 128, 32 x 128, 64 x 64): the same numbers as the product of
+    the rounded operands held in fp32"""
     g = torch.Generator(device="cuda").manual_seed(rows + 1)
     dY = torch.randn(rows, N, device="cuda", generator=g).bfloat16()
     X = torch.randn(rows + 50, K, device="cuda", generator=g)
@@ -728,17 +729,19 @@ def test_gemm_bf16_wgrad_stored_kmajor(rows, N, K, b_half, span_limit):
     assert (out2 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
     # beyond the 32-bit span of a K-major operand: accumulating K chunks, advanced in 2-byte elements (no gather: a gathered
     # operand cannot be rebased)
-    span_limit(rows * N * 2 // 3 + 4096)
-    out3 = torch.zeros(N, K, device="cuda")
-    _gemm(dY, Xs, out3, N, K, rows, akm=1, bkm=1, acc=1, bf16=True)
-    span_limit(0)
-    assert (out3 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
+    if rows >= 1000:  # (a chunk is at least one 64-row K step)
+        span_limit(rows * max(N * 2, K * (2 if b_half else 4)) // 3 + 4096)  # about three chunks of the wider operand
+        out3 = torch.zeros(N, K, device="cuda")
+        _gemm(dY, Xs, out3, N, K, rows, akm=1, bkm=1, acc=1, bf16=True)
+        span_limit(0)
+        assert (out3 - ref2).abs().max() <= 1e-5 * rows ** 0.5 * 4 + 1e-4
     # a small corner of it (the tail of a chunked contraction): same tile, one K range
     small = torch.zeros(64, 64, device="cuda")
-    _gemm(dY, Xs, small, 64, 64, 200, akm=1, bkm=1, acc=1, bf16=True)
-    assert (small - _ref_bf16(dY.float()[:200, :64].t(), X[:200, :64])).abs().max() <= 2e-4
+    nc, kk = min(64, N, K), min(200, rows)
+    _gemm(dY, Xs, small, nc, nc, kk, akm=1, bkm=1, acc=1, bf16=True)
+    assert (small[:nc, :nc] - _ref_bf16(dY.float()[:kk, :nc].t(), X[:kk, :nc])).abs().max() <= 2e-4
     with pytest.raises(L.DvaeHipError, match="accumulating weight-gradient"):
-        _gemm(dY, Xs, small, 64, 64, 200, akm=1, bkm=1, acc=0, bf16=True)
+        _gemm(dY, Xs, small, nc, nc, kk, akm=1, bkm=1, acc=0, bf16=True)
 
 
 @pytest.mark.parametrize("rows,Hp", [(1024, 512), (100, 64), (7, 32), (333, 1024)])
