@@ -194,7 +194,9 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dh, int ld_dh, const fl
             st4h(oh + Hp + c, dZ);
             st4h(oh + 2 * Hp + c, dGN);
         }
-        st4(dgin + (long)r * Hp + c, dPN);
+        // (half grads -- no fp32 d gh: d pre_n goes out as bf16 too; dgin then points at bf16 words)
+        if (dgh) st4(dgin + (long)r * Hp + c, dPN);
+        else stg4<true>(dgin, (long)r * Hp + c, dPN);
         if (dhprev) st4(dhprev + (long)r * ld_dhprev + c, dHP);
     }
 }
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(1024) void type_csr_kernel(const int* __restrict__ 
 //   bhn[0:Hp]      += sum over all rows of dgh[:, 2Hp:3Hp]          (d (W_hn h + b_hn))
 //   gi[t][2Hp:3Hp] += sum over rows of type t of dgin               (d pre_n)
 // grid (ceil(Hp / 64) column blocks of 64 float4, row chunks, T); partial sums are added with atomics.
-// GH: dgh points at bf16 words (the backward tails' bf16-only d gh: train.hip half_grads()); dgin stays fp32
+// GH: dgh and dgin point at bf16 words (the backward tails' bf16-only gradients: train.hip half_grads())
 template <bool GH>
 __global__ __launch_bounds__(256) void type_colsum_kernel(const float* __restrict__ dgh, const float* __restrict__ dgin,
                                                           const int* __restrict__ off, const int* __restrict__ idx,
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void type_colsum_kernel(const float* __restric
     const long ld = in_gh ? 3 * Hp : Hp;
     const long c0 = in_gh ? col : col - 3 * Hp;
     auto row = [&](int r) -> float4 {
-        if (GH && in_gh) return ldg4<true>(dgh, c0 + r * ld);
+        if (GH) return ldg4<true>(in_gh ? dgh : dgin, c0 + r * ld);
         return ld4((in_gh ? dgh : dgin) + c0 + r * ld);
     };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -689,7 +691,7 @@ extern "C" int dvae_type_colsum(const float* dgh, const float* dgin, const int32
                                 float* gi, float* bhn, int32_t rows, int32_t Hp, void* stream) {
     return dvae::type_colsum_h(dgh, dgin, off, idx, T, gi, bhn, rows, Hp, (hipStream_t)stream, 0);
 }
-// gh: dgh points at bf16 words
+// gh: dgh and dgin point at bf16 words
 int dvae::type_colsum_h(const float* dgh, const float* dgin, const int32_t* off, const int32_t* idx, int32_t T, float* gi,
                         float* bhn, int32_t rows, int32_t Hp, hipStream_t stream, int gh) {
     if (rows == 0) return DVAE_OK;

@@ -515,7 +515,7 @@ static bool half_gates(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_GATES_BF16"); return v ? atoi(v) : 1; }();
     return knob && act_shadows(d, B) && bf16_weight_copies_on() && !chain_fused(d, B) && !chain_fused_bwd(d, B);
 }
-// HALF GRADS (on top of half gates; DVAE_GRADS_BF16=0: off): d gh / d gm exist ONLY as the bf16 arrays that were their
+// HALF GRADS (on top of half gates; DVAE_GRADS_BF16=0: off): d gh / d gm (and d pre_n, `dgin`) exist ONLY as bf16 -- the arrays that were their
 // shadows -- the weight-gradient products rounded them to bf16 on the way to LDS anyway (now: gemm_bf16.hip's bf16-stored
 // K-major loaders, with the state / predecessor-sum shadows on the other side), the data gradients already read the
 // shadows, and the per-type / per-level column sums read bf16 (type_colsum_kernel<true>, segment_colsum_kernel<true>).
@@ -864,7 +864,7 @@ extern "C" int dvae_encode_backward(const dvae_model_desc* m, const dvae_batch_c
                                         w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp, s));
         else
             DVAE_TRY(gru_pointwise_bwd_h(dhs, Hp, hoff(w.gates[k], r0 * 3 * Hp, hg), hoff(w.ghn[k], r0 * Hp, hg), w.agg[k] + r0 * Hp,
-                                         Hp, gh ? nullptr : w.dgh[k] + r0 * 3 * Hp, w.dgin[k] + r0 * Hp, w.dagg[k] + r0 * Hp, Hp, B, Hp,
+                                         Hp, gh ? nullptr : w.dgh[k] + r0 * 3 * Hp, hoff(w.dgin[k], r0 * Hp, gh), w.dagg[k] + r0 * Hp, Hp, B, Hp,
                                          (step > 0 || gh) ? dgh_h : nullptr, s, hg));
         if (step > 0 && fused) {
             // d agg += d gh W_hh, then -- same launch -- the gate/mapper pointwise backward of the level
@@ -1261,7 +1261,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
         const bool hg = half_gates(d, B);  // as dvae_loss_forward saved them (false whenever fused)
         const bool gh = half_grads(d, B);  // d gh / d gm as bf16 only
         DVAE_TRY(gru_pointwise_bwd_h(w.dst + p0 * Hp, Hp, hoff(w.gates, p0 * 3 * Hp, hg), hoff(w.ghn, p0 * Hp, hg), w.agg + p0 * Hp,
-                                     Hp, gh ? nullptr : w.dgh + p0 * 3 * Hp, w.dgin + p0 * Hp, w.dagg + p0 * Hp, Hp, PT, Hp,
+                                     Hp, gh ? nullptr : w.dgh + p0 * 3 * Hp, hoff(w.dgin, p0 * Hp, gh), w.dagg + p0 * Hp, Hp, PT, Hp,
                                      dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, s, hg));
         DVAE_TRY(lin_dgrad(w.dgh + p0 * 3 * Hp, 3 * Hp, whh, Hp, w.dagg + p0 * Hp, Hp, nullptr, PT, 3 * Hp, Hp, 1, s, nullptr,
                            dgh_h ? dgh_h + p0 * 3 * Hp : nullptr, gh));
@@ -1314,7 +1314,7 @@ extern "C" int dvae_loss_backward(const dvae_model_desc* m, const dvae_batch_cou
                                             w.dagg + r0 * Hp, Hp, B, Hp, s));
             else
                 DVAE_TRY(gru_pointwise_bwd_h(dst, Hp, hoff(w.gates, r0 * 3 * Hp, hg), hoff(w.ghn, r0 * Hp, hg), w.agg + r0 * Hp, Hp,
-                                             gh ? nullptr : w.dgh + r0 * 3 * Hp, w.dgin + r0 * Hp, w.dagg + r0 * Hp, Hp, B, Hp,
+                                             gh ? nullptr : w.dgh + r0 * 3 * Hp, hoff(w.dgin, r0 * Hp, gh), w.dagg + r0 * Hp, Hp, B, Hp,
                                              dgh_h ? dgh_h + r0 * 3 * Hp : nullptr, s, hg));
             if (fused) {
                 dvae_level_desc da = {};
