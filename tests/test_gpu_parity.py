@@ -295,10 +295,14 @@ def test_max_size_graphs_n64_match_oracle():
 BF16_TOL_LOSS, BF16_TOL_LATENT, BF16_TOL_GRAD = 5e-3, 2e-2, 6e-2
 
 
-@pytest.mark.parametrize("cls,bidir,var", [("DVAE", True, True), ("DVAE_BN", False, False)])
-def test_bf16_mode_close_to_oracle(cls, bidir, var):
+# (B = 288: more than 256 graphs per batch take the bf16-mode path of the large configurations WITHOUT any forcing --
+# product + pointwise launches per level, bf16 shadows, half gates, half grads, per-level side-stream products:
+# csrc/train.hip act_shadows / half_gates / half_grads / loss_by_level)
+@pytest.mark.parametrize("cls,bidir,var,B", [("DVAE", True, True, 48), ("DVAE_BN", False, False, 48), ("DVAE", True, False, 288),
+                                             ("DVAE", False, True, 288)])
+def test_bf16_mode_close_to_oracle(cls, bidir, var, B):
     rng = np.random.default_rng(12)
-    n, T, hs, nz, B = 9, 7, 72, 10, 48
+    n, T, hs, nz = 9, 7, 72, 10
     ctor = dict(max_n=n, nvt=T, START_TYPE=0, END_TYPE=1, hs=hs, nz=nz, bidirectional=int(bidir))
     model = make_model(cls, ctor, 3)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
