@@ -45,6 +45,9 @@ pmj = {k: {"mean": v[0], "launches": v[1]} for k, v in pm.items()}
 pmj["shape_MNK"] = [9251, 2048, 512]  # tools/profile_round.sh: gemm_one.py 9251 2048 512 (the EB product of cfg 2)
 json.dump(pmj, open(os.path.join(D, "%s_gemm_pmc.json" % r), "w"), indent=1)
 
+if os.path.exists(os.path.join(P, "chain_pmc.json")):  # tools/pmc_chain_json.sh: the GRU level kernel alone
+    shutil.copy(os.path.join(P, "chain_pmc.json"), os.path.join(D, "%s_chain_pmc.json" % r))
+
 allp = os.path.join(ROOT, "gpurun_out", "bench_all.jsonl")
 if os.path.exists(allp):
     out = {}

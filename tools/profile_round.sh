@@ -47,3 +47,5 @@ cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain_alone -o s -- python3 $R/tools/chain_bench.py 1024 512 > $O/chain_alone.log 2>&1 || exit 1
 cp $O/chain_alone/s_kernel_stats.csv $O/chain_level_alone_kernel_stats.csv || exit 1
 cd $R
+# 7. PMC traffic of the GRU level kernel alone (BENCH.roofline.traffic)
+bash tools/pmc_chain_json.sh > $O/pmc_chain_json.log 2>&1 || exit 1
