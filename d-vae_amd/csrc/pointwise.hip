@@ -357,12 +357,13 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(float* __restrict__
 }
 
 // Several column sums in ONE launch (the bias gradients of the loss backward: four reductions whose inputs are all final at
-// the same point of the stream): blockIdx.z picks the job, each job has its own chunking; out[c] += scale * sum_rows x[row][c].
+// the same point of the stream): a 1-D grid, each job owns the run of workgroups [first, first + xblocks * chunks) with its
+// own chunking; out[c] += scale * sum_rows x[row][c].
 struct ColsumJob {
     float* out;
     const void* x;
     const float* scale;  // nullable: one device float
-    int ld_x, rows, w4, rows_per_chunk, chunks, x_bf16;
+    int ld_x, rows, w4, rows_per_chunk, chunks, x_bf16, first, xblocks;
 };
 struct ColsumJobs {
     ColsumJob j[4];
@@ -381,11 +382,15 @@ __device__ __forceinline__ float4 colsum_rows(const void* x, int ld_x, long base
 }
 __global__ __launch_bounds__(256) void colsum_jobs_kernel(ColsumJobs J) {
     __shared__ float4 red[4][64];
-    const ColsumJob& jb = J.j[blockIdx.z];
-    if ((int)blockIdx.x * 64 >= jb.w4 || (int)blockIdx.y >= jb.chunks) return;  // (whole workgroups: before the barrier)
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (J.j[i].chunks > 0 && (int)blockIdx.x >= J.j[i].first) ji = i;
+    const ColsumJob& jb = J.j[ji];
+    const int local = (int)blockIdx.x - jb.first, bx = local % jb.xblocks, by = local / jb.xblocks;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c4 = blockIdx.x * 64 + tx;
-    const int r0 = blockIdx.y * jb.rows_per_chunk, r1 = min(r0 + jb.rows_per_chunk, jb.rows);
+    const int c4 = bx * 64 + tx;
+    const int r0 = by * jb.rows_per_chunk, r1 = min(r0 + jb.rows_per_chunk, jb.rows);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < jb.w4)
         acc = jb.x_bf16 ? colsum_rows<true>(jb.x, jb.ld_x, c4 * 4L, r0, r1, ty) : colsum_rows<false>(jb.x, jb.ld_x, c4 * 4L, r0, r1, ty);
@@ -720,7 +725,7 @@ namespace dvae {
 int colsum_jobs(const ColsumJobDesc* jobs, int n, hipStream_t s) {
     DVAE_REQUIRE(jobs && n >= 0 && n <= 4, "colsum_jobs: 0 .. 4 jobs");
     ColsumJobs J = {};
-    int nj = 0, gx = 1, gy = 1;
+    int nj = 0, total = 0;
     for (int i = 0; i < n; ++i) {
         const ColsumJobDesc& d = jobs[i];
         if (d.rows == 0) continue;
@@ -735,11 +740,12 @@ int colsum_jobs(const ColsumJobDesc* jobs, int n, hipStream_t s) {
         if (chunks > cap) chunks = cap;
         j.rows_per_chunk = cdiv(d.rows, chunks);
         j.chunks = cdiv(d.rows, j.rows_per_chunk);
-        if (xb > gx) gx = xb;
-        if (j.chunks > gy) gy = j.chunks;
+        j.xblocks = xb;
+        j.first = total;
+        total += xb * j.chunks;
     }
     if (nj == 0) return DVAE_OK;
-    hipLaunchKernelGGL(colsum_jobs_kernel, dim3(gx, gy, nj), dim3(256), 0, s, J);
+    hipLaunchKernelGGL(colsum_jobs_kernel, dim3(total), dim3(256), 0, s, J);
     DVAE_LAUNCH_CHECK();
     return DVAE_OK;
 }
