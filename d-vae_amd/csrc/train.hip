@@ -260,7 +260,8 @@ struct EncWs {
 // (DVAE_ACT_BF16=0: fp32 activations converted on their way into LDS, as in round 2; =2: at every batch size -- tests)
 static bool act_shadows(const Dims& d, int B) {
     static const int knob = [] { const char* v = getenv("DVAE_ACT_BF16"); return v ? atoi(v) : 1; }();
-    return knob && d.bf16 && !d.bn && (B > 256 || knob == 2) && d.Hp % 8 == 0;
+    // (the products read a shadow only beside the bf16 weight copy: DVAE_BF16_WEIGHTS=0 turns the shadows off too)
+    return knob && bf16_weight_copies_on() && d.bf16 && !d.bn && (B > 256 || knob == 2) && d.Hp % 8 == 0;
 }
 static EncWs carve_enc(const Dims& d, const dvae_batch_counts& c, float* base) {
     EncWs w;
